@@ -1,0 +1,273 @@
+"""Pins oracle/ref_cpu.py against the fixtures generated from the reference itself
+(tools/make_goldens.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from tests import util as U
+from scpair_amd import synth
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    if a.shape != b.shape and a.numel() == b.numel():
+        b = b.reshape(a.shape)        # the reference's 1-D theta path returns [1,N] (scVI_distribution.py:51-54)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    both_nan = torch.isnan(a) & torch.isnan(b)
+    both_inf = torch.isinf(a) & torch.isinf(b) & (torch.sign(a) == torch.sign(b))
+    ok = both_nan | both_inf | ((a - b).abs() <= atol + rtol * b.abs())
+    assert bool(ok.all()), f"max abs diff {(a - b)[~ok].abs().max()} at {int((~ok).sum())} of {a.numel()}"
+
+
+def test_kat_values():
+    d = U.load("kat_likelihood")
+    x = torch.tensor([0., 1., 5.]); mu = torch.tensor([.5, 2., 3.]); th = torch.tensor([1., 2., .5])
+    close(O.log_nb(x, mu, th), d["kat_nb"])
+    close(O.log_nb(x, mu, th), [-0.40546510, -1.38629436, -3.14575100], rtol=1e-6)
+    close(O.log_zinb(x, mu, th, torch.tensor([0., -1., 2.])), d["kat_zinb"])
+    close(O.log_zinb(x, mu, th, torch.tensor([0., -1., 2.])), [-0.18232155, -1.69955587, -5.27267885], rtol=1e-6)
+    b = U.load("kat_bce_mse")
+    close(O.bce_masked(torch.tensor([0., 1., 1.]), torch.tensor([0.2, 0.9, 1e-9])), b["kat_bce"])
+    close(O.mse_masked(torch.tensor([1., float("nan"), 3.]), torch.tensor([0., 5., 1.])), 2.5)
+
+
+@pytest.mark.parametrize("tag,dt", [("f32", torch.float32), ("f64", torch.float64)])
+def test_likelihood_grid(tag, dt):
+    d = U.load("kat_likelihood")
+    x, mu, th, pi = [torch.tensor(d[k], dtype=dt) for k in ("x", "mu", "theta", "pi")]
+    tol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=1e-10, atol=1e-10)
+    close(O.log_nb(x, mu, th), d[f"nb_{tag}"], **tol)
+    close(O.log_zinb(x, mu, th, pi), d[f"zinb_{tag}"], **tol)
+    if dt == torch.float64:
+        gm, gt = O.nb_grad(x, mu, th)
+        close(gm, d["nb_dmu_f64"], rtol=1e-8, atol=1e-8)
+        close(gt, d["nb_dtheta_f64"], rtol=1e-6, atol=1e-7)
+        gm, gt, gp = O.zinb_grad(x, mu, th, pi)
+        close(gm, d["zinb_dmu_f64"], rtol=1e-8, atol=1e-8)
+        close(gt, d["zinb_dtheta_f64"], rtol=1e-6, atol=1e-7)
+        close(gp, d["zinb_dpi_f64"], rtol=1e-8, atol=1e-8)
+
+
+def test_bce_mse():
+    b = U.load("kat_bce_mse")
+    p = torch.tensor(b["bce_p"]); x = torch.tensor(b["bce_x"])
+    close(O.bce_masked(x, p), b["bce_loss"])
+    close(O.bce_grad(x, p), b["bce_dp"], rtol=1e-5, atol=1e-9)
+    close(O.mse_masked(torch.tensor(b["mse_x"]), torch.tensor(b["mse_mu"])), b["mse_loss"])
+
+
+def test_layer_norm_grad():
+    torch.manual_seed(0)
+    x = torch.randn(5, 12, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(12, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(12, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(5, 12, dtype=torch.float64)
+    y = torch.nn.functional.layer_norm(x, (12,), w, b)
+    close(O.layer_norm(x, w, b), y, rtol=1e-10)
+    gx, gw, gb = torch.autograd.grad((y * dy).sum(), [x, w, b])
+    dx, dw, db = O.layer_norm_grad(x.detach(), w.detach(), dy)
+    close(dx, gx, rtol=1e-9, atol=1e-12); close(dw, gw, rtol=1e-9); close(db, gb, rtol=1e-9)
+
+
+def _req(sd):
+    for v in sd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    return sd
+
+
+def _check_grads(sd, grads, rtol=2e-4, atol=2e-6):
+    for k, g in grads.items():
+        if sd[k].grad is None:
+            continue
+        close(sd[k].grad, g, rtol=rtol, atol=atol)
+
+
+def test_input_module():
+    d = U.load("mod_input")
+    for tag in json.loads(str(d["cases"])):
+        c = U.cfg(d, f"{tag}/cfg")
+        sd = _req(U.sub(d, f"{tag}/sd"))
+        x, cov = torch.tensor(d[f"{tag}/x"]), U.opt(d, f"{tag}/cov")
+        rep, lat = O.input_module(sd, x, cov, True, c["bn"], 0.01, training=True)
+        close(rep, d[f"{tag}/rep"], rtol=1e-4, atol=1e-5)
+        loss = (rep * torch.tensor(d[f"{tag}/w_rep"])).sum()
+        if c["lib"]:
+            close(lat, d[f"{tag}/lat"], rtol=1e-4, atol=1e-5)
+            loss = loss + (lat * torch.tensor(d[f"{tag}/w_lat"])).sum()
+        else:
+            assert lat is None
+        loss.backward()
+        _check_grads(sd, U.sub(d, f"{tag}/grad"), rtol=1e-3, atol=1e-4)
+        if c["bn"]:
+            for k, v in U.sub(d, f"{tag}/sd_after").items():
+                close(sd[k].detach(), v, rtol=1e-5, atol=1e-6)
+        with torch.no_grad():
+            rep_e, lat_e = O.input_module(sd, x, cov, True, c["bn"], 0.01, training=False)
+        close(rep_e, d[f"{tag}/rep_eval"], rtol=1e-4, atol=1e-5)
+
+
+def test_output_ber():
+    d = U.load("mod_ber")
+    for tag in json.loads(str(d["cases"])):
+        c = U.cfg(d, f"{tag}/cfg")
+        sd = _req(U.sub(d, f"{tag}/sd"))
+        h = torch.tensor(d[f"{tag}/h"], requires_grad=True)
+        latlib = U.opt(d, f"{tag}/latlib")
+        if latlib is not None:
+            latlib.requires_grad_(True)
+        res = O.output_ber(sd, h, U.opt(d, f"{tag}/cov"), U.opt(d, f"{tag}/lib"), latlib, c["sf"])
+        close(res[0], d[f"{tag}/out0"]); close(res[1], d[f"{tag}/out1"])
+        y = torch.tensor(d[f"{tag}/y"])
+        loss = O.bce_masked(y, res[0])
+        close(loss, d[f"{tag}/loss"])
+        loss.backward()
+        close(h.grad, d[f"{tag}/dh"], rtol=1e-4, atol=1e-7)
+        _check_grads(sd, U.sub(d, f"{tag}/grad"))
+        if f"{tag}/dlatlib" in d.files:
+            close(latlib.grad, d[f"{tag}/dlatlib"], rtol=1e-4, atol=1e-7)
+        # closed-form dL/dp agrees with autograd
+        p = res[0].detach().requires_grad_(True)
+        (g,) = torch.autograd.grad(O.bce_masked(y, p), p)
+        close(O.bce_grad(y, p.detach()), g, rtol=1e-5, atol=1e-9)
+
+
+def test_output_raw():
+    d = U.load("mod_raw")
+    for tag in json.loads(str(d["cases"])):
+        c = U.cfg(d, f"{tag}/cfg")
+        sd = _req(U.sub(d, f"{tag}/sd"))
+        h = torch.tensor(d[f"{tag}/h"], requires_grad=True)
+        latlib = U.opt(d, f"{tag}/latlib")
+        if latlib is not None:
+            latlib.requires_grad_(True)
+        scale, theta, rate, pi = O.output_raw(sd, h, U.opt(d, f"{tag}/cov"), U.opt(d, f"{tag}/lib"), latlib,
+                                              c["sf"], c["disp"])
+        close(scale, d[f"{tag}/scale"], rtol=1e-5, atol=1e-8)
+        close(theta, d[f"{tag}/theta"] if c["disp"] == "feature-cell" else d[f"{tag}/theta"])
+        close(rate, d[f"{tag}/rate"], rtol=1e-5, atol=1e-7)
+        y = torch.tensor(d[f"{tag}/y"])
+        loss = O.raw_loss(y, rate, theta, pi, c["lik"])
+        close(loss, d[f"{tag}/loss"])
+        loss.backward()
+        close(h.grad, d[f"{tag}/dh"], rtol=1e-3, atol=1e-6)
+        _check_grads(sd, U.sub(d, f"{tag}/grad"), rtol=1e-3, atol=1e-6)
+        if latlib is not None:
+            close(latlib.grad, d[f"{tag}/dlatlib"], rtol=1e-3, atol=1e-6)
+
+
+def test_gau_and_mapping():
+    d = U.load("mod_gau_map")
+    for i in range(3):
+        tag = f"gau{i}"
+        sd = _req(U.sub(d, f"{tag}/sd"))
+        h = torch.tensor(d[f"{tag}/h"], requires_grad=True)
+        out = O.output_gau(sd, h, U.opt(d, f"{tag}/cov"), None)
+        close(out, d[f"{tag}/out"])
+        loss = O.mse_masked(torch.tensor(d[f"{tag}/y"]), out)
+        close(loss, d[f"{tag}/loss"])
+        loss.backward()
+        close(h.grad, d[f"{tag}/dh"], rtol=1e-4, atol=1e-7)
+        _check_grads(sd, U.sub(d, f"{tag}/grad"))
+    for i in range(4):
+        tag = f"map{i}"
+        c = U.cfg(d, f"{tag}/cfg")
+        sd = _req(U.sub(d, f"{tag}/sd"))
+        x = torch.tensor(d[f"{tag}/x"], requires_grad=True)
+        pred = O.module_module(sd, x, c["nonneg"], c["ln"], c["bn"], 0.01, training=True)
+        close(pred, d[f"{tag}/pred"], rtol=1e-4, atol=1e-6)
+        loss = O.mse_masked(torch.tensor(d[f"{tag}/y"]), pred)
+        loss.backward()
+        close(x.grad, d[f"{tag}/dx"], rtol=1e-3, atol=1e-6)
+        _check_grads(sd, U.sub(d, f"{tag}/grad"), rtol=1e-3, atol=1e-6)
+
+
+def test_vae_modules():
+    d = U.load("mod_vae")
+    for i in range(int(d["ncases"])):
+        tag = f"c{i}"
+        c = U.cfg(d, f"{tag}/cfg")
+        esd = _req(U.sub(d, f"{tag}/enc_sd")); dsd = _req(U.sub(d, f"{tag}/dec_sd"))
+        x = torch.tensor(d[f"{tag}/x"])
+        mu, sigma, z, lat = O.vae_encoder(esd, x, torch.tensor(d[f"{tag}/eps"]))
+        close(mu, d[f"{tag}/mu"], rtol=1e-4, atol=1e-6); close(sigma, d[f"{tag}/sigma"], rtol=1e-4, atol=1e-6)
+        close(z, d[f"{tag}/z"], rtol=1e-4, atol=1e-6)
+        outs = O.vae_decoder(dsd, z, None, U.opt(d, f"{tag}/lib"), lat, c["dist"], c["disp"], sample_factor=not c["infer"])
+        kl = O.kl_normal(mu, sigma)
+        close(kl, d[f"{tag}/kl"], rtol=1e-5)
+        if c["dist"] == "gau":
+            recon = O.mse_masked(x, outs)
+        else:
+            scale, theta, rate, pi = outs
+            close(rate, d[f"{tag}/rate"], rtol=1e-4, atol=1e-7); close(theta, d[f"{tag}/theta"], rtol=1e-4, atol=1e-7)
+            recon = O.raw_loss(x, rate, theta, pi, c["dist"])
+        close(recon, d[f"{tag}/recon"], rtol=1e-5)
+        (c["kl_weight"] * kl + recon).backward()
+        _check_grads(esd, U.sub(d, f"{tag}/enc_grad"), rtol=2e-3, atol=1e-5)
+        _check_grads(dsd, U.sub(d, f"{tag}/dec_grad"), rtol=2e-3, atol=1e-5)
+
+
+def test_weight_decay_groups_and_adamw():
+    import os
+    with open(os.path.join(U.GOLD, "weight_decay_groups.json")) as f:
+        groups = json.load(f)
+    for name, g in groups.items():
+        if name.startswith("__"):
+            continue
+        ol = "bias" if name.endswith("[bias]") else ["output"]
+        fixed = list(g["ndim"].items())
+        dec, nodec = O.weight_decay_split(fixed, ol)
+        assert sorted(dec) == sorted(g["decay"]) and sorted(nodec) == sorted(g["nodecay"]), name
+    d = U.load("adamw_traj")
+    params = {"a": torch.tensor(d["init_0"]), "b": torch.tensor(d["init_1"])}
+    opt = O.AdamW(params, ["a"], lr=1e-3, wd=1e-2)
+    for s in range(5):
+        opt.step({"a": torch.tensor(d[f"g{s}_0"]), "b": torch.tensor(d[f"g{s}_1"])})
+        close(params["a"], d[f"p{s}_0"], rtol=1e-6, atol=1e-7)
+        close(params["b"], d[f"p{s}_1"], rtol=1e-6, atol=1e-7)
+    close(opt.m["a"], d["m_final_0"], rtol=1e-5, atol=1e-8)
+    close(opt.v["a"], d["v_final_0"], rtol=1e-5, atol=1e-10)
+
+
+def _traj_data(c):
+    data = synth.make_paired(c["n"], c["g"], c["p"], seed=c["seed"], p_atac=c["p_atac"])
+    dense = {}
+    for split in ("train", "val", "test"):
+        idx = data[split]
+        dense[split] = (torch.tensor(np.asarray(data["rna"][idx].todense(), dtype=np.float32)),
+                        torch.tensor(np.asarray(data["atac"][idx].todense(), dtype=np.float32)))
+    return data, dense
+
+
+@pytest.mark.parametrize("name", ["traj_zinb_ber", "traj_nb_ber", "traj_nb_ber_bn", "traj_nb_ber_cov"])
+def test_training_trajectory(name):
+    d = U.load(name)
+    c = U.cfg(d, "cfg")
+    data, dense = _traj_data(c)
+    cov = {s: (torch.tensor(d["cov"][data[s]]) if c["with_cov"] else None) for s in ("train", "val")}
+    liks = list(c["modalities"].values())
+    for di in range(2):
+        x_i, y_i = (0, 1) if di == 0 else (1, 0)
+        lik = liks[1 - di]
+        xtr, ytr = dense["train"][x_i], dense["train"][y_i]
+        xva, yva = dense["val"][x_i], dense["val"][y_i]
+        use_lib = lik in ("nb", "zinb")                 # sample_factor_rna=True / sample_factor_atac=False
+        libtr = ytr.sum(1, keepdim=True) if use_lib else None
+        libva = yva.sum(1, keepdim=True) if use_lib else None
+        direction = O.Direction(U.sub(d, f"dir{di}/enc_init"), U.sub(d, f"dir{di}/dec_init"), lik,
+                                dict(batchnorm=c["batchnorm"], sample_factor=use_lib))
+        batches = U.split_batches(d[f"dir{di}/batch_rows"], d[f"dir{di}/batch_sizes"])
+        tl, vl, best = O.run_direction(direction, xtr, ytr, libtr, xva, yva, libva, batches, c["epochs"],
+                                       cov["train"], cov["val"])
+        close(tl, d[f"dir{di}/train_loss"], rtol=2e-4, atol=1e-6)
+        close(vl, d[f"dir{di}/val_loss"], rtol=2e-4, atol=1e-6)
+        for k, v in U.sub(d, f"dir{di}/enc_final").items():
+            if v.dtype.is_floating_point:
+                close(best[0][k], v, rtol=5e-3, atol=2e-4)
+        emb = O.input_module(best[0], xtr, cov["train"], True, c["batchnorm"], 0.01, False)[0]
+        key = "emb/" + list(c["modalities"].keys())[di] + "_train"
+        close(emb.detach(), d[key], rtol=5e-3, atol=1e-3)

@@ -177,6 +177,8 @@ def gold_input_module():
                 if p_.ndim == 1:
                     p_.add_(0.1 * torch.randn_like(p_))
         enc.train()
+        tag = f"c{ci}"
+        out.update(sd_arrays(enc, f"{tag}/sd"))     # BEFORE the training-mode forward (BN running stats)
         x = toy_counts(100 + ci)
         cov = toy_cov(200 + ci) if c["cov"] else None
         rep, lat = enc(x, cov)
@@ -187,9 +189,7 @@ def gold_input_module():
             w_lat = torch.randn_like(lat)
             loss = loss + (lat * w_lat).sum()
         loss.backward()
-        tag = f"c{ci}"
         names.append(tag)
-        out.update(sd_arrays(enc, f"{tag}/sd"))
         out.update(grad_arrays(enc, f"{tag}/grad"))
         out.update({f"{tag}/x": x, f"{tag}/cov": cov, f"{tag}/rep": rep, f"{tag}/lat": lat,
                     f"{tag}/w_rep": w_rep, f"{tag}/w_lat": w_lat,
@@ -406,22 +406,22 @@ def gold_optimizer():
                            layernorm=True, batchnorm=True, dropout_rate=0.1, add_linear_layer=True,
                            infer_library_size=True)
     _, _, d, nd = ref.add_weight_decay(enc, output_layer=["output"])
-    groups["Input_Module"] = {"decay": d, "nodecay": nd}
+    groups["Input_Module"] = {"decay": d, "nodecay": nd, "ndim": {k: v.ndim for k, v in enc.named_parameters()}}
     raw = ref.Output_Module_Raw(output_dim=G, output_batch_num=0, hidden_layer=H, infer_library_size=False,
                                 sample_factor=True, feature_factor=True, zero_inflated=True, dispersion="feature-cell")
     _, _, d, nd = ref.add_weight_decay(raw, output_layer=["output"])
-    groups["Output_Module_Raw"] = {"decay": d, "nodecay": nd}
+    groups["Output_Module_Raw"] = {"decay": d, "nodecay": nd, "ndim": {k: v.ndim for k, v in raw.named_parameters()}}
     ber = ref.Output_Module_Ber(output_dim=P, output_batch_num=0, hidden_layer=H, infer_library_size=True,
                                 sample_factor=False, feature_factor=True)
     _, _, d, nd = ref.add_weight_decay(ber, output_layer=["output"])
-    groups["Output_Module_Ber"] = {"decay": d, "nodecay": nd}
+    groups["Output_Module_Ber"] = {"decay": d, "nodecay": nd, "ndim": {k: v.ndim for k, v in ber.named_parameters()}}
     gau = ref.Output_Module_Gau(output_dim=G, output_batch_num=0, hidden_layer=H, infer_library_size=False, feature_factor=True)
     _, _, d, nd = ref.add_weight_decay(gau, output_layer=["output"])
-    groups["Output_Module_Gau"] = {"decay": d, "nodecay": nd}
+    groups["Output_Module_Gau"] = {"decay": d, "nodecay": nd, "ndim": {k: v.ndim for k, v in gau.named_parameters()}}
     mp = ref.Module_Module(origin_module_dim=8, target_module_dim=8, translational_hidden_nodes=[12], non_neg=False,
                            layernorm=True, activation=nn.LeakyReLU(), batchnorm=False, dropout_rate=0)
     _, _, d, nd = ref.add_weight_decay(mp, output_layer="bias")
-    groups["Module_Module[bias]"] = {"decay": d, "nodecay": nd}
+    groups["Module_Module[bias]"] = {"decay": d, "nodecay": nd, "ndim": {k: v.ndim for k, v in mp.named_parameters()}}
     groups["__torch_version__"] = torch.__version__
     with open(os.path.join(OUT, "weight_decay_groups.json"), "w") as f:
         json.dump(groups, f, indent=1)
@@ -433,7 +433,7 @@ def gold_optimizer():
     params = [nn.Parameter(torch.tensor(a)) for a in p0]
     opt = torch.optim.AdamW([{"params": [params[0]], "weight_decay": 1e-2, "lr": 1e-3},
                              {"params": [params[1]], "weight_decay": 0, "lr": 1e-3}])
-    out = {"p0_0": p0[0], "p0_1": p0[1]}
+    out = {"init_0": p0[0], "init_1": p0[1]}
     for step in range(5):
         gs = [(rng.normal(size=a.shape) * (10.0 ** rng.integers(-4, 2))).astype(np.float32) for a in p0]
         for p_, g_ in zip(params, gs):
