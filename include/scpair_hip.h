@@ -1,0 +1,123 @@
+/* scpair_hip.h -- C ABI of the MI355X-native scPair training hot path (libscpair_hip.so).
+ *
+ * The reference (quon-titative-biology/scPair) is pure Python on PyTorch and has no FFI of its own;
+ * the seam it exposes is Python level.  Each entry point below replaces the
+ * ATen-op chain behind one reference construct, cited as  <reference file>:<lines>.
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory (HBM) unless a parameter says "host"; fp32 unless stated
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work (no sync, no malloc)
+ *   - caller owns all buffers, including workspaces whose sizes the *_len / *_ws_* helpers return
+ *   - return 0 on success, negative on error (SCP_ERR_*); scp_last_error() gives the message
+ *   - `ns` selects MFMA input precision: 1 = bf16 inputs, 3 = bf16 hi+mid+lo split of every fp32
+ *     operand (6 MFMAs per product, fp32-equivalent); accumulation is always fp32
+ *   - a "tile list" (t_ptr, t_key, t_val) is the minibatch re-bucketing built by scp_tiles_build
+ */
+#ifndef SCPAIR_HIP_H
+#define SCPAIR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* scp_last_error(void);
+int scp_version(void);
+
+/* ---- minibatch assembly: replaces LazyGPUDataset.__getitem__ + default_collate + .to(device)
+ *      (model.py:26-38, 704-717, 731-732) and the dense `lib = mtx.sum(1)` (model.py:509-510) ---- */
+long scp_tiles_ptr_len(int B, int F);   /* int32 elements needed for `ptr` */
+long scp_tiles_ws_len(int B, int F);    /* int32 elements needed for `ws`  */
+int scp_tiles_build(const int64_t* indptr, const int32_t* indices, const float* values /* null: implicit 1 */,
+                    const int64_t* rows, int B, int F, int32_t* ptr, int32_t* key, float* val /* nullable */,
+                    float* lib /* [B] row sums, nullable */, int32_t* nnan /* [1], nullable */, int32_t* ws,
+                    void* stream);
+
+/* ---- first encoder layer on sparse counts: nn.Linear(F_in, H) of FCNN (utils.py:57) applied to
+ *      the dense x in Input_Module (model.py:128-130, 136-140), forward and weight gradient ---- */
+int scp_gemm_split_count(int K, int nsplit);   /* slabs actually produced for a requested nsplit */
+int scp_spmm_fwd(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
+                 const float* W /* [N][w_sr] */, long w_sr, float* Y /* [nsplit][ncells][ldy] */, long ldy,
+                 const float* bias /* nullable, added to slab 0 */, int nsplit, int ns, void* stream);
+int scp_spmm_dw(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
+                const float* dY /* [ncells][ldy] */, long ldy, float* dW /* [N][ldw] */, long ldw, int ns,
+                void* stream);
+
+/* ---- dense layers: nn.Linear forward / dgrad / wgrad (utils.py:57; model.py:84, 92, 163, 217, 228,
+ *      280, 331; pairedVAE.py:49-50, 111-119) as one strided GEMM  C[M,N] (+)= A[M,K] B[N,K]^T + bias ---- */
+int scp_gemm_nt(int M, int N, int K, const float* A, long a_row_stride, long a_k_stride, const float* B,
+                long b_row_stride, long b_k_stride, float* C, long ldc, const float* bias /* [N] nullable */,
+                int accumulate, int nsplit, int ns, void* stream);
+int scp_slab_reduce(const float* slabs, long slab_stride, int nslab, int rows, int cols, long ld,
+                    const float* bias, float* out, long ldo, void* stream);
+int scp_colsum(const float* X, long ld, int rows, int cols, float* out, float* partials_ws /* [32*cols] */,
+               void* stream);
+
+/* ---- FCNN layer epilogue: [LayerNorm] -> LeakyReLU(slope)/ReLU(0) -> Dropout (utils.py:58-63),
+ *      fused with the split-K slab reduction and the bias add; gamma/beta null = no LayerNorm ---- */
+int scp_ln_act_fwd(const float* Y, long ldy, long slab_stride, int nslab, const float* bias, const float* gamma,
+                   const float* beta, int B, int H, float eps, float slope, float p_drop, uint64_t seed,
+                   float* xhat /* [B][ldx] saved for backward, nullable */, long ldx, float* rstd /* [B] */,
+                   float* out, long ldo, void* stream);
+int scp_ln_act_bwd_grid(int B);   /* partials_ws needs grid*3*H floats */
+int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, long ldx, const float* rstd, const float* gamma,
+                   const float* beta, int B, int H, float slope, float p_drop, uint64_t seed, float* dY, long ldy,
+                   float* dgamma, float* dbeta, float* dbias /* each [H], nullable */, float* partials_ws,
+                   void* stream);
+
+/* ---- Bernoulli decoder + BCE, fused forward(+backward): Output_Module_Ber.forward (model.py:164-190)
+ *      + binarized_loss (loss.py:36-41, BCELoss log clamp -100, NaN labels masked) ---- */
+int scp_dec_chunks(int F);
+int scp_dec_kp(int K);
+long scp_dec_ws_floats(int B, int F, int K);
+long scp_dec_ws_doubles(int F);
+int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, long ldh, const float* W, long ldw,
+                    const float* bias, const float* fs /* feature_scalar, nullable */,
+                    const float* lrow /* lib or latent_lib logits, nullable */, int lrow_n /* 0, 1 or B */,
+                    const int32_t* t_ptr, const int32_t* t_key, const float* t_val, const int32_t* nnan,
+                    const float* gout /* nullable = 1 */, float* loss /* [1] */, float* dW, long lddw, float* db,
+                    float* dfs, float* dh, long lddh, float* dlrow, float* ws_f, double* ws_d, int ns, void* stream);
+
+/* ---- NB decoder + log-likelihood, fused: Output_Module_Raw.forward without zero inflation
+ *      (model.py:229-259) + raw_loss('nb') (loss.py:46-48) + log_nb_positive (scVI_distribution.py:74-105) ---- */
+int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, long ldh, const float* W, long ldw,
+                  const float* bias, const float* fs, const float* theta_param /* dispersion='feature', nullable */,
+                  const float* lrow /* [B] library size L */, const float* lat /* latent_lib or null */,
+                  const int32_t* t_ptr, const int32_t* t_key, const float* t_val, const float* gout, float* loss,
+                  float* dW, long lddw, float* db, float* dfs, float* dtheta, float* dh, long lddh, float* dlat,
+                  float* rowbuf /* [2*B] */, float* ws_f, double* ws_d, int ns, void* stream);
+
+/* ---- masked MSE: scaled_loss (loss.py:22-27) ---- */
+int scp_mse_masked_fwd(const float* x, long ldx, const float* mu, long ldm, int rows, int cols,
+                       float* loss_cnt /* [2]: mean, count */, double* ws /* >= 520 */, void* stream);
+int scp_mse_masked_bwd(const float* x, long ldx, const float* mu, long ldm, int rows, int cols,
+                       const float* loss_cnt, const float* gout, float* dmu, long ldd, void* stream);
+
+/* ---- VAE bottleneck: softplus + 1e-7, reparameterise (pairedVAE.py:51-58), KL mean (utils.py:186) ---- */
+int scp_reparam_kl_fwd(const float* mu, const float* sraw, const float* eps, long n, float* sigma, float* z,
+                       float* kl /* [1] */, double* ws /* >= 520 */, void* stream);
+int scp_reparam_kl_bwd(const float* mu, const float* sraw, const float* eps, const float* sigma, const float* dz,
+                       const float* dmu_in, const float* gkl, long n, float* dmu, float* dsraw, void* stream);
+
+/* ---- decoder heads for predict() (model.py:558-591) ---- */
+int scp_ber_prob(const float* z, long ldz, int rows, int cols, const float* lrow, int lrow_n, const float* fs,
+                 float* out, long ldo, void* stream);
+int scp_relu_softmax_rows(const float* z, long ldz, int rows, int cols, const float* fs, int apply_relu,
+                          float* scale, long lds, float* theta /* nullable */, long ldt, void* stream);
+
+/* ---- optimiser: torch.optim.AdamW step as the trainer configures it (model.py:698-701, 849-850, 982) ---- */
+#define SCP_ADAM_MAX_TENSORS 24
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long n;
+  float lr, weight_decay, bias_corr1, bias_corr2, grad_scale;
+} ScpAdamTensor;
+int scp_adamw_multi(const ScpAdamTensor* tensors /* host array */, int n, float beta1, float beta2, float eps,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

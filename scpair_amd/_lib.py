@@ -1,0 +1,107 @@
+"""ctypes binding of libscpair_hip.so (C ABI declared in include/scpair_hip.h).
+
+There is NO fallback: if the library is missing, importing any compute entry point raises.  The
+binding passes raw device pointers (tensor.data_ptr()) and torch's current HIP stream; torch is used
+only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscpair_hip.so")
+
+_lib = None
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+F = C.c_float
+U64 = C.c_uint64
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", L),
+                ("lr", F), ("weight_decay", F), ("bias_corr1", F), ("bias_corr2", F), ("grad_scale", F)]
+
+
+_SIGS = {
+    "scp_last_error": (C.c_char_p, []),
+    "scp_version": (I, []),
+    "scp_tiles_ptr_len": (L, [I, I]),
+    "scp_tiles_ws_len": (L, [I, I]),
+    "scp_tiles_build": (I, [P, P, P, P, I, I, P, P, P, P, P, P, P]),
+    "scp_gemm_split_count": (I, [I, I]),
+    "scp_spmm_fwd": (I, [I, I, I, P, P, P, P, L, P, L, P, I, I, P]),
+    "scp_spmm_dw": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
+    "scp_gemm_nt": (I, [I, I, I, P, L, L, P, L, L, P, L, P, I, I, I, P]),
+    "scp_slab_reduce": (I, [P, L, I, I, I, L, P, P, L, P]),
+    "scp_colsum": (I, [P, L, I, I, P, P, P]),
+    "scp_ln_act_fwd": (I, [P, L, L, I, P, P, P, I, I, F, F, F, U64, P, L, P, P, L, P]),
+    "scp_ln_act_bwd_grid": (I, [I]),
+    "scp_ln_act_bwd": (I, [P, L, P, L, P, P, P, I, I, F, F, U64, P, L, P, P, P, P, P]),
+    "scp_dec_chunks": (I, [I]),
+    "scp_dec_kp": (I, [I]),
+    "scp_dec_ws_floats": (L, [I, I, I]),
+    "scp_dec_ws_doubles": (L, [I]),
+    "scp_ber_dec_bce": (I, [I, I, I, I, P, L, P, L, P, P, P, I, P, P, P, P, P, P, P, L, P, P, P, L, P, P, P, I, P]),
+    "scp_nb_dec_ll": (I, [I, I, I, I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, L, P, P, P, P, I, P]),
+    "scp_mse_masked_fwd": (I, [P, L, P, L, I, I, P, P, P]),
+    "scp_mse_masked_bwd": (I, [P, L, P, L, I, I, P, P, P, L, P]),
+    "scp_reparam_kl_fwd": (I, [P, P, P, L, P, P, P, P, P]),
+    "scp_reparam_kl_bwd": (I, [P, P, P, P, P, P, P, L, P, P, P]),
+    "scp_ber_prob": (I, [P, L, I, I, P, I, P, P, L, P]),
+    "scp_relu_softmax_rows": (I, [P, L, I, I, P, I, P, L, P, L, P]),
+    "scp_adamw_multi": (I, [C.POINTER(AdamTensor), I, F, F, F, P]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """The loaded shared library (raises if it has not been built: `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with scpair_amd/csrc/build.sh "
+                               "(there is no CPU/eager fallback for the HIP kernels)")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+class ScpError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().scp_last_error().decode()
+        if rc in (-1,):
+            raise ValueError(f"{what}: {msg}")
+        raise ScpError(f"{what}: error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("scpair_amd HIP kernels need tensors in GPU memory (got a CPU tensor); "
+                               "there is no CPU fallback")

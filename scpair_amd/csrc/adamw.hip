@@ -1,0 +1,91 @@
+// Fused multi-tensor AdamW (torch.optim.AdamW defaults as the reference uses them, model.py:698-701:
+// betas (0.9, 0.999), eps 1e-8, amsgrad False, decoupled decay p *= 1 - lr*wd).
+// HBM-bound: 16 B read (p, g, m, v) + 12 B written (p, m, v) per parameter = 28 B/param/step.
+// Up to SCP_ADAM_MAX_TENSORS tensors per launch, descriptors passed by value (no host->device copy).
+#include "common.h"
+#include "scpair_hip.h"
+
+#define ADAM_CHUNK 4096   // elements per workgroup: 256 threads x 4 x float4
+
+struct AdamPack {
+  ScpAdamTensor t[SCP_ADAM_MAX_TENSORS];
+  int chunk_start[SCP_ADAM_MAX_TENSORS + 1];
+  int n;
+  float beta1, beta2, eps;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
+  int blk = blockIdx.x;
+  int ti = 0;
+#pragma unroll 1
+  while (ti + 1 < pk.n && blk >= pk.chunk_start[ti + 1]) ti++;
+  const ScpAdamTensor t = pk.t[ti];
+  long base = (long)(blk - pk.chunk_start[ti]) * ADAM_CHUNK;
+  float b1 = pk.beta1, b2 = pk.beta2;
+  float decay = 1.f - t.lr * t.weight_decay;
+  float step_size = t.lr / t.bias_corr1;
+  float inv_sqrt_bc2 = 1.f / sqrtf(t.bias_corr2);
+  bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    long i = base + (long)it * 1024 + threadIdx.x * 4;
+    if (i >= t.n) break;
+    if (vec && i + 4 <= t.n) {
+      float4 p = *(float4*)(t.p + i), g = *(const float4*)(t.g + i), m = *(float4*)(t.m + i), v = *(float4*)(t.v + i);
+      float pa[4] = {p.x, p.y, p.z, p.w}, ga[4] = {g.x, g.y, g.z, g.w}, ma[4] = {m.x, m.y, m.z, m.w},
+            va[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float gk = ga[k] * t.grad_scale;
+        pa[k] *= decay;
+        ma[k] = ma[k] + (gk - ma[k]) * (1.f - b1);
+        va[k] = va[k] * b2 + gk * gk * (1.f - b2);
+        float denom = sqrtf(va[k]) * inv_sqrt_bc2 + pk.eps;
+        pa[k] -= step_size * (ma[k] / denom);
+      }
+      *(float4*)(t.p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+      *(float4*)(t.m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+      *(float4*)(t.v + i) = make_float4(va[0], va[1], va[2], va[3]);
+    } else {
+      for (int k = 0; k < 4 && i + k < t.n; k++) {
+        float gk = t.g[i + k] * t.grad_scale;
+        float p = t.p[i + k] * decay;
+        float m = t.m[i + k];
+        m = m + (gk - m) * (1.f - b1);
+        float v = t.v[i + k] * b2 + gk * gk * (1.f - b2);
+        float denom = sqrtf(v) * inv_sqrt_bc2 + pk.eps;
+        t.p[i + k] = p - step_size * (m / denom);
+        t.m[i + k] = m;
+        t.v[i + k] = v;
+      }
+    }
+  }
+}
+
+extern "C" int scp_adamw_multi(const ScpAdamTensor* tensors, int n, float beta1, float beta2, float eps,
+                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SCP_CHECK(tensors && n > 0, SCP_ERR_ARG, "scp_adamw_multi: no tensors");
+  for (int o = 0; o < n; o += SCP_ADAM_MAX_TENSORS) {
+    AdamPack pk;
+    pk.n = 0;
+    pk.beta1 = beta1; pk.beta2 = beta2; pk.eps = eps;
+    int chunks = 0;
+    for (int i = o; i < n && pk.n < SCP_ADAM_MAX_TENSORS; i++) {
+      const ScpAdamTensor& t = tensors[i];
+      SCP_CHECK(t.p && t.g && t.m && t.v, SCP_ERR_ARG, "scp_adamw_multi: null pointer in tensor %d", i);
+      SCP_CHECK(t.n >= 0, SCP_ERR_ARG, "scp_adamw_multi: negative size in tensor %d", i);
+      SCP_CHECK(t.bias_corr1 > 0.f && t.bias_corr2 > 0.f, SCP_ERR_ARG, "scp_adamw_multi: bias corrections must be > 0");
+      if (t.n == 0) continue;
+      pk.t[pk.n] = t;
+      pk.chunk_start[pk.n] = chunks;
+      chunks += (int)((t.n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+      pk.n++;
+    }
+    pk.chunk_start[pk.n] = chunks;
+    if (chunks == 0) continue;
+    hipLaunchKernelGGL(adamw_kernel, dim3(chunks), dim3(256), 0, stream, pk);
+    SCP_LAUNCH_CHECK();
+  }
+  return SCP_OK;
+}

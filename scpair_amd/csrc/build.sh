@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libscpair_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/../libscpair_hip.so"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wno-unused-result"
+OBJ="$HERE/build"
+mkdir -p "$OBJ"
+pids=()
+for f in capi gemm tiles norm_act adamw elementwise decoder decoder_ber_ns1 decoder_ber_ns3 decoder_nb_ns1 decoder_nb_ns3; do
+  if [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/decoder_kernel.h" -nt "$OBJ/$f.o" ] || [ "$ROOT/include/scpair_hip.h" -nt "$OBJ/$f.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/*.o
+echo "built $OUT"

@@ -1,0 +1,158 @@
+// Shared device helpers for the scPair hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SCP_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- error plumbing (host side) -----------------------------------------------------------
+void scp_set_error(const char* fmt, ...);
+#define SCP_CHECK(cond, code, ...)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      scp_set_error(__VA_ARGS__);             \
+      return (code);                          \
+    }                                         \
+  } while (0)
+#define SCP_HIP(expr)                                                        \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      scp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                    __FILE__, __LINE__);                                     \
+      return -100;                                                           \
+    }                                                                        \
+  } while (0)
+#define SCP_LAUNCH_CHECK() SCP_HIP(hipGetLastError())
+
+enum {
+  SCP_OK = 0,
+  SCP_ERR_ARG = -1,      // bad argument (null pointer, negative size, unsupported flag)
+  SCP_ERR_SHAPE = -2,    // shape outside what the kernel supports
+  SCP_ERR_HIP = -100     // HIP runtime error, see scp_last_error()
+};
+
+// ---- bf16 split: f = hi + mid + lo (each bf16), 24 significant bits in total ----------------
+template <int NS>
+__device__ __forceinline__ void bf16_split(float f, __bf16* out) {
+  __bf16 h = (__bf16)f;
+  out[0] = h;
+  if (NS > 1) {
+    float r = f - (float)h;
+    __bf16 m = (__bf16)r;
+    out[1] = m;
+    if (NS > 2) {
+      float r2 = r - (float)m;
+      out[2] = (__bf16)r2;
+    }
+  }
+}
+
+// Which (a-term, b-term) products are kept for an NS-term split: all pairs with i + j < NS
+// NS=1: (0,0)            -> bf16 inputs, fp32 accumulate
+// NS=2: (0,0)(0,1)(1,0)  -> ~16 significant bits per operand
+// NS=3: 6 products       -> fp32-equivalent (dropped terms <= 2^-24 relative)
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// C/D element mapping of the 32x32 MFMA accumulator (dtype independent on gfx950):
+//   col = lane & 31 ; row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ---- wave / block reductions -------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 32 lanes that share (lane >> 5)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in thread 0. `red` >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x < 64) {
+    r = (l < (int)(blockDim.x >> 6)) ? red[l] : 0.f;
+    r = wave_sum(r);
+  }
+  return r;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  v = wave_sum_d(v);
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x < 64) {
+    r = (l < (int)(blockDim.x >> 6)) ? red[l] : 0.0;
+    r = wave_sum_d(r);
+  }
+  return r;
+}
+
+// ---- special functions -----------------------------------------------------------------------
+// softplus with torch's threshold (F.softplus default beta=1, threshold=20)
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// digamma for x > 0 (the only domain the likelihood kernels need): recurrence up to x >= 6, then
+// the asymptotic series  ln x - 1/(2x) - 1/(12x^2) + 1/(120x^4) - 1/(252x^6) + 1/(240x^8) - 1/(132x^10)
+__device__ __forceinline__ float digammaf_pos(float x) {
+  float acc = 0.f;
+  while (x < 6.f) {
+    acc -= 1.f / x;
+    x += 1.f;
+  }
+  float r = 1.f / x, r2 = r * r;
+  float ser = r2 * (1.f / 12.f - r2 * (1.f / 120.f - r2 * (1.f / 252.f - r2 * (1.f / 240.f - r2 * (1.f / 132.f)))));
+  return acc + logf(x) - 0.5f * r - ser;
+}
+
+// lgamma(x+theta) - lgamma(theta) - lgamma(x+1) for integer-valued x >= 1, computed so that the
+// catastrophic cancellation lgamma(x+theta)-lgamma(theta) at large theta is avoided for small x:
+//   lgamma(x+theta)-lgamma(theta) = sum_{i<x} log(theta+i)   (exact identity for integer x)
+// For large x fall back to lgammaf differences (what the reference computes).
+__device__ __forceinline__ float lgamma_terms(float x, float theta) {
+  return lgammaf(x + theta) - lgammaf(theta) - lgammaf(x + 1.f);
+}
+
+// counter-based RNG for dropout masks: one 32-bit hash per (seed, element index); reproducible in backward
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p) {
+  if (p <= 0.f) return 1.f;
+  float u = (float)(hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? 1.f / (1.f - p) : 0.f;
+}

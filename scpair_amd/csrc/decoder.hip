@@ -1,0 +1,173 @@
+// Host API of the fused decoder kernels (kernels: decoder_kernel.h, instantiated per precision in
+// decoder_{ber,nb}_ns{1,3}.hip).
+#include "decoder_kernel.h"
+
+int dec_run_ber_ns1(int mode, const DecArgs& g, int kp, int grid, hipStream_t stream);
+int dec_run_ber_ns3(int mode, const DecArgs& g, int kp, int grid, hipStream_t stream);
+int dec_run_nb_ns1(int mode, const DecArgs& g, int kp, int grid, hipStream_t stream);
+int dec_run_nb_ns3(int mode, const DecArgs& g, int kp, int grid, hipStream_t stream);
+
+template <int MODE>
+static int dec_dispatch(const DecArgs& g, int ns, int grid, hipStream_t stream) {
+  SCP_CHECK(g.K <= 64, SCP_ERR_SHAPE, "decoder: latent+covariate width K=%d > 64 unsupported", g.K);
+  int kp = g.K <= 16 ? 16 : (g.K <= 48 ? 48 : 64);
+  SCP_CHECK(!(ns == 3 && kp == 64), SCP_ERR_SHAPE, "decoder: K=%d > 48 needs ns = 1 (LDS budget)", g.K);
+  SCP_CHECK(ns == 1 || ns == 3, SCP_ERR_ARG, "decoder: ns must be 1 or 3 (got %d)", ns);
+  constexpr bool ber = (MODE == MODE_BER_TRAIN || MODE == MODE_BER_EVAL);
+  if (ber) return ns == 1 ? dec_run_ber_ns1(MODE, g, kp, grid, stream) : dec_run_ber_ns3(MODE, g, kp, grid, stream);
+  return ns == 1 ? dec_run_nb_ns1(MODE, g, kp, grid, stream) : dec_run_nb_ns3(MODE, g, kp, grid, stream);
+}
+
+// ---- finishing kernels ------------------------------------------------------------------------------
+// dh[b][k] = sum_chunk slab[chunk][b][k]
+__global__ __launch_bounds__(256) void dec_finish_dh_kernel(const float* __restrict__ slab, int nchunk, int B, int K, int KP,
+                                                            float* __restrict__ dh, long lddh) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * K) return;
+  int b = (int)(i / K), k = (int)(i % K);
+  float s = 0.f;
+  for (int c = 0; c < nchunk; c++) s += slab[((long)c * B + b) * KP + k];
+  dh[(long)b * lddh + k] = s;
+}
+
+// row_mode 0: out0[b] = sum_chunk slab[.][b][0]                    (Ber dl / NB T)
+// row_mode 1: (m,s) merge -> out0[b] = m + log s                    (NB log-sum-exp)
+// row_mode 2: like 0, and out1[b] = out0[b] * dscale(lat[b])        (NB dlatent_lib = T * lrelu'(lat))
+__global__ __launch_bounds__(256) void dec_finish_rows_kernel(const float* __restrict__ slab, int nchunk, int B,
+                                                              int row_mode, float scale_, const float* __restrict__ aux,
+                                                              float* __restrict__ out0, float* __restrict__ out1) {
+  int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  if (row_mode == 1) {
+    float m = -INFINITY, s = 0.f;
+    for (int c = 0; c < nchunk; c++) {
+      float m2 = slab[((long)c * B + b) * 2], s2 = slab[((long)c * B + b) * 2 + 1];
+      float mn = fmaxf(m, m2);
+      float e1 = (m == -INFINITY) ? 0.f : expf(m - mn), e2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+      s = s * e1 + s2 * e2;
+      m = mn;
+    }
+    out0[b] = m + logf(s);
+  } else {
+    float s = 0.f;
+    for (int c = 0; c < nchunk; c++) s += slab[((long)c * B + b) * 2];
+    out0[b] = s;
+    if (row_mode == 2 && out1) out1[b] = s * scale_ * ((aux[b] > 0.f) ? 1.f : 0.01f);
+  }
+}
+
+__global__ void dec_finish_loss_kernel(const double* __restrict__ sum, double n_total, const int32_t* __restrict__ nnan,
+                                       float* __restrict__ loss) {
+  double n = n_total - (nnan ? (double)nnan[0] : 0.0);
+  loss[0] = (float)(sum[0] / n);
+}
+
+int scp_reduce_partials(const double* part, int n, int ncomp, double* out, hipStream_t stream);
+
+extern "C" int scp_dec_chunks(int F) { return (F + DEC_NPT * FT - 1) / (DEC_NPT * FT); }
+extern "C" int scp_dec_kp(int K) { return K <= 16 ? 16 : (K <= 48 ? 48 : 64); }
+
+static int check_common(const char* who, int B, int F, int K, const float* h, const float* W, const float* bias,
+                        const void* ws) {
+  SCP_CHECK(B > 0 && F > 0 && K > 0, SCP_ERR_ARG, "%s: sizes must be positive (B=%d F=%d K=%d)", who, B, F, K);
+  SCP_CHECK(h && W && bias && ws, SCP_ERR_ARG, "%s: null pointer", who);
+  return SCP_OK;
+}
+
+// Workspace layout (floats unless noted), nchunk = scp_dec_chunks(F), KP = scp_dec_kp(K):
+//   ws_d  : doubles  [nchunk + 8]
+//   ws_f  : floats   [nchunk*B*KP + nchunk*B*2]
+extern "C" long scp_dec_ws_floats(int B, int F, int K) {
+  long nchunk = scp_dec_chunks(F);
+  return nchunk * (long)B * scp_dec_kp(K) + nchunk * (long)B * 2;
+}
+extern "C" long scp_dec_ws_doubles(int F) { return scp_dec_chunks(F) + 8; }
+
+extern "C" int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, long ldh, const float* W, long ldw,
+                               const float* bias, const float* fs, const float* lrow, int lrow_n, const int32_t* t_ptr,
+                               const int32_t* t_key, const float* t_val, const int32_t* nnan, const float* gout,
+                               float* loss, float* dW, long lddw, float* db, float* dfs, float* dh, long lddh,
+                               float* dlrow, float* ws_f, double* ws_d, int ns, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("scp_ber_dec_bce", B, F, K, h, W, bias, ws_d);
+  if (rc) return rc;
+  SCP_CHECK(t_ptr && t_key && loss, SCP_ERR_ARG, "scp_ber_dec_bce: null pointer");
+  SCP_CHECK(!train || (dW && db && dh && ws_f), SCP_ERR_ARG, "scp_ber_dec_bce: training needs dW, db, dh, ws_f");
+  SCP_CHECK(lrow_n == 0 || lrow_n == 1 || lrow_n == B, SCP_ERR_ARG, "scp_ber_dec_bce: lrow_n must be 0, 1 or B");
+  int nchunk = scp_dec_chunks(F), KP = scp_dec_kp(K);
+  DecArgs g = {};
+  g.B = B; g.F = F; g.K = K; g.h = h; g.ldh = ldh; g.W = W; g.ldw = ldw; g.bias = bias; g.fs = fs;
+  g.lrow = lrow; g.lrow_n = lrow_n; g.t_ptr = t_ptr; g.t_key = t_key; g.t_val = t_val; g.nnan = nnan; g.gout = gout;
+  g.loss_part = ws_d; g.dW = dW; g.lddw = lddw; g.db = db; g.dfs = dfs;
+  g.dh_slab = ws_f; g.row_slab = ws_f ? ws_f + (long)nchunk * B * KP : nullptr;
+  rc = train ? dec_dispatch<MODE_BER_TRAIN>(g, ns, nchunk, stream) : dec_dispatch<MODE_BER_EVAL>(g, ns, nchunk, stream);
+  if (rc) return rc;
+  rc = scp_reduce_partials(ws_d, nchunk, 1, ws_d + nchunk, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dec_finish_loss_kernel, dim3(1), dim3(1), 0, stream, ws_d + nchunk, (double)B * (double)F, nnan, loss);
+  SCP_LAUNCH_CHECK();
+  if (train) {
+    hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, stream, g.dh_slab,
+                       nchunk, B, K, KP, dh, lddh);
+    SCP_LAUNCH_CHECK();
+    if (dlrow && lrow && lrow_n == B) {
+      hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, g.row_slab, nchunk, B, 0, 1.f,
+                         (const float*)nullptr, dlrow, (float*)nullptr);
+      SCP_LAUNCH_CHECK();
+    }
+  }
+  return SCP_OK;
+}
+
+// NB decoder (zero_inflated=False path / likelihood 'nb'): loss = -mean log NB(y; L*softmax(a'), theta)
+//   lrow = library size L per cell (sample_factor) or exp(leaky_relu(latent_lib)) precomputed by the caller
+//   lat  = latent_lib (only to form dlat = T * L'(lat) / ... ; null when lrow is data)
+extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, long ldh, const float* W, long ldw,
+                             const float* bias, const float* fs, const float* theta_param, const float* lrow,
+                             const float* lat, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
+                             const float* gout, float* loss, float* dW, long lddw, float* db, float* dfs, float* dtheta,
+                             float* dh, long lddh, float* dlat, float* rowbuf /* [2*B] */, float* ws_f, double* ws_d,
+                             int ns, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common("scp_nb_dec_ll", B, F, K, h, W, bias, ws_d);
+  if (rc) return rc;
+  SCP_CHECK(t_ptr && t_key && loss && lrow && rowbuf && ws_f, SCP_ERR_ARG, "scp_nb_dec_ll: null pointer");
+  SCP_CHECK(!train || (dW && db && dh), SCP_ERR_ARG, "scp_nb_dec_ll: training needs dW, db, dh");
+  int nchunk = scp_dec_chunks(F), KP = scp_dec_kp(K);
+  DecArgs g = {};
+  g.B = B; g.F = F; g.K = K; g.h = h; g.ldh = ldh; g.W = W; g.ldw = ldw; g.bias = bias; g.fs = fs;
+  g.theta_param = theta_param; g.lrow = lrow; g.lrow_n = B; g.t_ptr = t_ptr; g.t_key = t_key; g.t_val = t_val;
+  g.gout = gout; g.loss_part = ws_d; g.dW = dW; g.lddw = lddw; g.db = db; g.dfs = dfs; g.dtheta = dtheta;
+  g.dh_slab = ws_f; g.row_slab = ws_f + (long)nchunk * B * KP;
+  float* lse = rowbuf;
+  float* T = rowbuf + B;
+  // pass 1: row log-sum-exp
+  rc = dec_dispatch<MODE_NB_STATS>(g, ns, nchunk, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, g.row_slab, nchunk, B, 1, 1.f,
+                     (const float*)nullptr, lse, (float*)nullptr);
+  SCP_LAUNCH_CHECK();
+  // pass 2: loss and T
+  g.rowlse = lse;
+  rc = dec_dispatch<MODE_NB_LOSS>(g, ns, nchunk, stream);
+  if (rc) return rc;
+  rc = scp_reduce_partials(ws_d, nchunk, 1, ws_d + nchunk, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dec_finish_loss_kernel, dim3(1), dim3(1), 0, stream, ws_d + nchunk, (double)B * (double)F,
+                     (const int32_t*)nullptr, loss);
+  SCP_LAUNCH_CHECK();
+  if (!train) return SCP_OK;
+  // dlat = d loss / d latent_lib = -(1/N) * T * lrelu'(lat)   (L = exp(lrelu(lat)) => dL/dlat = L*lrelu', dll/dL = T/L)
+  float sc = -1.f / ((float)B * (float)F);
+  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, g.row_slab, nchunk, B,
+                     (dlat && lat) ? 2 : 0, sc, lat, T, dlat);
+  SCP_LAUNCH_CHECK();
+  // pass 3: gradients
+  g.rowT = T;
+  rc = dec_dispatch<MODE_NB_GRAD>(g, ns, nchunk, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, stream, g.dh_slab,
+                     nchunk, B, K, KP, dh, lddh);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}

@@ -1,0 +1,432 @@
+// Fused linear decoder + likelihood kernels (gfx950).
+//
+//   Bernoulli decoder + BCE      : model.py:164-190 (Output_Module_Ber) + loss.py:36-41
+//   (ZI)NB decoder + log-lik     : model.py:229-259 (Output_Module_Raw) + loss.py:46-51,
+//                                  scVI_distribution.py:29-105
+//
+// The [cells x features] logits are never written to HBM.  A 256-thread workgroup owns a chunk of
+// NPT feature tiles (64 features each) and walks over all 64-cell blocks of the minibatch:
+//     Z tile (64x64)  = h_blk (64 x K) * W_tile^T          bf16 MFMA 32x32x16, fp32 accumulate
+//     epilogue        : bias, sigmoid / relu+softmax+NB terms, loss, dZ          (registers)
+//     dW tile (64xK) += dZ^T * h_blk   (accumulated in registers across ALL cell blocks -> complete)
+//     dh blk  (64xK) += dZ * W_tile    (accumulated across the chunk's tiles -> one slab per chunk)
+// Labels come from the minibatch tile list (tiles.hip) and are densified into LDS per (block, tile).
+// Reductions across workgroups are slabs summed in a fixed order by a finishing kernel, so results
+// are bitwise reproducible run to run.
+//
+// NB needs row statistics (softmax over ALL genes, model.py:242), so it runs as three passes over
+// the same skeleton, recomputing the K<=64 deep GEMM instead of storing [cells x genes] tensors:
+//     pass STATS : per-row log-sum-exp of a' = relu(z)*[sigmoid(fs)]
+//     pass LOSS  : log-likelihood sum, T_row = sum_j (dll/dmu_j * mu_j)
+//     pass GRAD  : dZ -> dW, dh, db (+ feature_scalar / feature-dispersion gradients)
+#pragma once
+#include "common.h"
+#include "scpair_hip.h"
+
+#define CB 64        // cells per block
+#define FT 64        // features per tile
+#define LDZ 72       // padded leading dim of the 64-wide bf16 images
+
+enum { MODE_BER_TRAIN = 0, MODE_BER_EVAL = 1, MODE_NB_STATS = 2, MODE_NB_LOSS = 3, MODE_NB_GRAD = 4 };
+
+struct DecArgs {
+  int B, F, K;                 // cells, output features, contraction depth (latent + covariates)
+  const float* h; long ldh;    // [B][K]
+  const float* W; long ldw;    // [F][K]
+  const float* bias;           // [F]
+  const float* fs;             // feature_scalar [F] or null
+  const float* lrow; int lrow_n;   // per-cell library term (Ber: logit; NB: library size L) or null
+  const float* rowlse;         // NB: per-cell log-sum-exp              [B]
+  const float* rowT;           // NB: per-cell T                        [B]
+  const float* theta_param;    // NB dispersion='feature': log theta    [F] or null (feature-cell)
+  // labels (tile list of the output modality)
+  const int32_t* t_ptr; const int32_t* t_key; const float* t_val;
+  const int32_t* nnan;         // device scalar: number of NaN labels (Ber) or null
+  const float* gout;           // upstream gradient scalar or null (=1)
+  // outputs
+  double* loss_part;           // [grid]
+  float* dW; long lddw;        // [F][K]
+  float* db;                   // [F]
+  float* dfs;                  // [F]
+  float* dtheta;               // [F]
+  float* dh_slab;              // [grid][B][KP]
+  float* row_slab;             // [grid][B][2]   (Ber: dl ; NB stats: m,s ; NB loss: T)
+};
+
+template <int NS>
+__device__ __forceinline__ void img_put(__bf16* img, int rows, int ld, int row, int col, float v) {
+  __bf16 t[3];
+  bf16_split<NS>(v, t);
+#pragma unroll
+  for (int s = 0; s < NS; s++) img[(s * rows + row) * ld + col] = t[s];
+}
+
+template <int NS, int KP, int NPT, int MODE>
+__global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
+  constexpr bool IS_BER = (MODE == MODE_BER_TRAIN || MODE == MODE_BER_EVAL);
+  constexpr bool TRAIN = (MODE == MODE_BER_TRAIN || MODE == MODE_NB_GRAD);
+  constexpr bool NEED_LABELS = (MODE != MODE_NB_STATS);
+  constexpr int LDK_ = KP + 8;
+  constexpr int NTK = (KP + 31) / 32;      // 32-wide column tiles covering K
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* hA = (__bf16*)smem_raw;                 // [NS][64][LDK_]   A of Z
+  __bf16* WB = hA + NS * CB * LDK_;               // [NS][64][LDK_]   B of Z
+  __bf16* hT = WB + NS * FT * LDK_;               // [NS][KP][LDZ]    B of dW   ([k][cell])
+  __bf16* WT = hT + NS * KP * LDZ;                // [NS][KP][LDZ]    B of dh   ([k][feature])
+  __bf16* dzA = WT + NS * KP * LDZ;               // [NS][64][LDZ]    A of dh   ([cell][feature])
+  __bf16* dzT = dzA + NS * CB * LDZ;              // [NS][64][LDZ]    A of dW   ([feature][cell])
+  float* ytile = (float*)(dzT + NS * FT * LDZ);   // [64][64]
+  float* rowv = ytile + CB * FT;                  // [3][64]  per-cell inputs
+  float* rred = rowv + 3 * CB;                    // [2][2][64] per-cell partial reductions
+  float* cred = ytile;                            // [2][NPT][3][64] per-feature partials; aliases ytile (used after the loops)
+  __shared__ double dred[8];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, hq = lane >> 5;
+  const int ti = wave >> 1, tj = wave & 1;        // Z tile: cell half, feature half
+  const int f_chunk0 = blockIdx.x * NPT * FT;
+  const int ncb = (g.B + CB - 1) / CB;
+
+  float inv_n = 1.f;
+  if (TRAIN) {
+    double n = (double)g.B * (double)g.F;
+    if (IS_BER && g.nnan) n -= (double)g.nnan[0];
+    inv_n = (float)((g.gout ? (double)g.gout[0] : 1.0) / n);
+  }
+
+  f32x16 accW[NPT];
+  float db_acc[NPT], dfs_acc[NPT], dth_acc[NPT];
+#pragma unroll
+  for (int t = 0; t < NPT; t++) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) accW[t][e] = 0.f;
+    db_acc[t] = dfs_acc[t] = dth_acc[t] = 0.f;
+  }
+  double loss_acc = 0.0;
+
+  for (int cb = 0; cb < ncb; cb++) {
+    const int c0 = cb * CB;
+    // ---- stage the h block (both layouts) and the per-cell inputs -------------------------------
+    for (int idx = tid; idx < CB * KP; idx += 256) {
+      int c = idx / KP, k = idx % KP;
+      float v = (c0 + c < g.B && k < g.K) ? g.h[(long)(c0 + c) * g.ldh + k] : 0.f;
+      img_put<NS>(hA, CB, LDK_, c, k, v);
+      if (TRAIN) img_put<NS>(hT, KP, LDZ, k, c, v);
+    }
+    if (tid < CB) {
+      int c = c0 + tid;
+      bool ok = c < g.B;
+      if (IS_BER) {
+        float l = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 0.f;
+        rowv[tid] = g.lrow ? sigmoidf_(l) : 1.f;
+      } else {
+        rowv[tid] = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 1.f;          // L
+        rowv[CB + tid] = (g.rowlse && ok) ? g.rowlse[c] : 0.f;                     // lse
+        rowv[2 * CB + tid] = (g.rowT && ok) ? g.rowT[c] : 0.f;                     // T
+      }
+    }
+    f32x16 accH;
+#pragma unroll
+    for (int e = 0; e < 16; e++) accH[e] = 0.f;
+    float racc0[16], racc1[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      racc0[e] = (MODE == MODE_NB_STATS) ? -INFINITY : 0.f;
+      racc1[e] = 0.f;
+    }
+
+#pragma unroll
+    for (int t = 0; t < NPT; t++) {
+      const int f0 = f_chunk0 + t * FT;
+      if (f0 >= g.F) break;                       // uniform
+      __syncthreads();                            // previous iteration's readers are done
+      // ---- stage W tile (both layouts), clear label tile ----------------------------------------
+      for (int idx = tid; idx < FT * KP; idx += 256) {
+        int p = idx / KP, k = idx % KP;
+        float v = (f0 + p < g.F && k < g.K) ? g.W[(long)(f0 + p) * g.ldw + k] : 0.f;
+        img_put<NS>(WB, FT, LDK_, p, k, v);
+        if (TRAIN) img_put<NS>(WT, KP, LDZ, k, p, v);
+      }
+      if (NEED_LABELS) {
+        float4 z4 = {0.f, 0.f, 0.f, 0.f};
+        for (int idx = tid; idx < CB * FT / 4; idx += 256) ((float4*)ytile)[idx] = z4;
+        __syncthreads();
+        long base = (long)cb * g.F;
+        int fend = min(f0 + FT, g.F);
+        int p0 = g.t_ptr[base + f0], p1 = g.t_ptr[base + fend];
+        for (int e = p0 + tid; e < p1; e += 256) {
+          int key = g.t_key[e];
+          float v = g.t_val ? g.t_val[e] : 1.f;
+          ytile[(key & 63) * FT + ((key >> 6) - f0)] = v;
+        }
+      }
+      __syncthreads();
+      // ---- Z = h W^T -----------------------------------------------------------------------------
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KP / 16; kk++) {
+        bf16x8 a[NS], b[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+          a[s] = *(const bf16x8*)&hA[(s * CB + ti * 32 + r) * LDK_ + kk * 16 + hq * 8];
+          b[s] = *(const bf16x8*)&WB[(s * FT + tj * 32 + r) * LDK_ + kk * 16 + hq * 8];
+        }
+#pragma unroll
+        for (int sa = 0; sa < NS; sa++)
+#pragma unroll
+          for (int sb = 0; sb < NS; sb++)
+            if (sa + sb < NS) acc = mfma32(a[sa], b[sb], acc);
+      }
+      // ---- epilogue ------------------------------------------------------------------------------
+      const int fl = tj * 32 + r;                 // feature inside tile
+      const int f = f0 + fl;
+      const bool f_ok = f < g.F;
+      const float bcol = f_ok ? g.bias[f] : 0.f;
+      float fcol = 1.f;
+      if (g.fs && f_ok) fcol = sigmoidf_(g.fs[f]);
+      float thcol = 0.f;
+      if (!IS_BER && g.theta_param && f_ok) thcol = expf(g.theta_param[f]);
+      float dzv[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int cl = ti * 32 + acc_row(e, lane);
+        const bool ok = f_ok && (c0 + cl < g.B);
+        dzv[e] = 0.f;
+        if (IS_BER) {
+          float zz = acc[e] + bcol;
+          float px = sigmoidf_(zz);
+          float sr = rowv[cl];
+          float q = px * sr * fcol;
+          float yv = ytile[cl * FT + fl];
+          if (ok && yv == yv) {
+            float lq = fmaxf(logf(q), -100.f), l1q = fmaxf(logf(1.f - q), -100.f);
+            loss_acc -= (double)(yv * lq + (1.f - yv) * l1q);
+            if (TRAIN) {
+              float dq = (q - yv) / fmaxf(q * (1.f - q), 1e-12f) * inv_n;
+              dzv[e] = dq * sr * fcol * px * (1.f - px);
+              racc0[e] += dq * px * fcol * sr * (1.f - sr);
+              dfs_acc[t] += dq * px * sr * fcol * (1.f - fcol);
+              db_acc[t] += dzv[e];
+            }
+          }
+        } else {
+          float zz = acc[e] + bcol;
+          float a_ = fmaxf(zz, 0.f);
+          float ap = a_ * fcol;
+          if (MODE == MODE_NB_STATS) {
+            if (ok) {
+              float m_old = racc0[e];
+              float m_new = fmaxf(m_old, ap);
+              racc1[e] = racc1[e] * expf(m_old - m_new) + expf(ap - m_new);
+              racc0[e] = m_new;
+            }
+          } else if (ok) {
+            const float eps = 1e-8f;
+            float L = rowv[cl], lse = rowv[CB + cl];
+            float scale = expf(ap - lse);
+            float mu = L * scale;
+            float th = g.theta_param ? thcol : expf(a_);
+            float s_ = th + mu + eps;
+            float lt = logf(th + eps), ls = logf(s_);
+            float yv = ytile[cl * FT + fl];
+            float gmu = -th / s_;
+            if (yv > eps) gmu += yv * (1.f / (mu + eps) - 1.f / s_);
+            if (MODE == MODE_NB_LOSS) {
+              float ll = th * (lt - ls);
+              if (yv > eps) ll += yv * (logf(mu + eps) - ls) + lgamma_terms(yv, th);
+              loss_acc -= (double)ll;
+              racc0[e] += gmu * mu;
+            } else {   // MODE_NB_GRAD
+              float gth = lt - ls + th / (th + eps) - th / s_;
+              if (yv > eps) gth += -yv / s_ + digammaf_pos(yv + th) - digammaf_pos(th);
+              float T = rowv[2 * CB + cl];
+              float dap = mu * gmu - scale * T;
+              float da = dap * fcol;
+              if (g.theta_param)
+                dth_acc[t] += -inv_n * gth * th;
+              else
+                da += gth * th;
+              float d = (zz > 0.f) ? -inv_n * da : 0.f;
+              dzv[e] = d;
+              db_acc[t] += d;
+              dfs_acc[t] += -inv_n * dap * a_ * fcol * (1.f - fcol);
+            }
+          }
+        }
+      }
+      if (TRAIN) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int cl = ti * 32 + acc_row(e, lane);
+          img_put<NS>(dzA, CB, LDZ, cl, fl, dzv[e]);
+          img_put<NS>(dzT, FT, LDZ, fl, cl, dzv[e]);
+        }
+        __syncthreads();
+        // ---- dW tile += dZ^T h ; dh block += dZ W -----------------------------------------------
+        const int mi = wave & 1, nj = wave >> 1;
+        if (nj < NTK) {
+          int brow = nj * 32 + r;
+          if (brow >= KP) brow = 0;
+#pragma unroll
+          for (int kk = 0; kk < CB / 16; kk++) {
+            bf16x8 a[NS], b[NS], a2[NS], b2[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+              a[s] = *(const bf16x8*)&dzT[(s * FT + mi * 32 + r) * LDZ + kk * 16 + hq * 8];
+              b[s] = *(const bf16x8*)&hT[(s * KP + brow) * LDZ + kk * 16 + hq * 8];
+              a2[s] = *(const bf16x8*)&dzA[(s * CB + mi * 32 + r) * LDZ + kk * 16 + hq * 8];
+              b2[s] = *(const bf16x8*)&WT[(s * KP + brow) * LDZ + kk * 16 + hq * 8];
+            }
+#pragma unroll
+            for (int sa = 0; sa < NS; sa++)
+#pragma unroll
+              for (int sb = 0; sb < NS; sb++)
+                if (sa + sb < NS) {
+                  accW[t] = mfma32(a[sa], b[sb], accW[t]);
+                  accH = mfma32(a2[sa], b2[sb], accH);
+                }
+          }
+        }
+      }
+    }  // feature tiles
+
+    // ---- per-cell results of this block ---------------------------------------------------------
+    if (TRAIN) {
+      const int mi = wave & 1, nj = wave >> 1;
+      if (nj < NTK) {
+        int k = nj * 32 + r;
+        if (k < g.K) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            int c = c0 + mi * 32 + acc_row(e, lane);
+            if (c < g.B) g.dh_slab[((long)blockIdx.x * g.B + c) * KP + k] = accH[e];
+          }
+        }
+      }
+    }
+    if (MODE == MODE_BER_TRAIN || MODE == MODE_NB_LOSS || MODE == MODE_NB_STATS) {
+      // combine the 32 lanes of each half, then the two waves sharing a cell half
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        float v0 = racc0[e], v1 = racc1[e];
+        if (MODE == MODE_NB_STATS) {
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            float m2 = __shfl_xor(v0, o, 64), s2 = __shfl_xor(v1, o, 64);
+            float mn = fmaxf(v0, m2);
+            float e1 = (v0 == -INFINITY) ? 0.f : expf(v0 - mn), e2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+            v1 = v1 * e1 + s2 * e2;
+            v0 = mn;
+          }
+        } else {
+          v0 = half_sum(v0);
+        }
+        if (r == 0) {
+          int cl = ti * 32 + acc_row(e, lane);
+          rred[(tj * 2 + 0) * CB + cl] = v0;
+          rred[(tj * 2 + 1) * CB + cl] = v1;
+        }
+      }
+      __syncthreads();
+      if (tid < CB && c0 + tid < g.B) {
+        float a0 = rred[0 * CB + tid], a1 = rred[1 * CB + tid], b0 = rred[2 * CB + tid], b1 = rred[3 * CB + tid];
+        float* dst = g.row_slab + ((long)blockIdx.x * g.B + c0 + tid) * 2;
+        if (MODE == MODE_NB_STATS) {
+          float mn = fmaxf(a0, b0);
+          float e1 = (a0 == -INFINITY) ? 0.f : expf(a0 - mn), e2 = (b0 == -INFINITY) ? 0.f : expf(b0 - mn);
+          dst[0] = mn;
+          dst[1] = a1 * e1 + b1 * e2;
+        } else {
+          dst[0] = a0 + b0;
+          dst[1] = 0.f;
+        }
+      }
+    }
+    __syncthreads();
+  }  // cell blocks
+
+  // ---- chunk-level outputs ------------------------------------------------------------------------
+  if (MODE != MODE_NB_STATS && MODE != MODE_NB_GRAD) {
+    double s = block_sum_d(loss_acc, dred);
+    if (tid == 0) g.loss_part[blockIdx.x] = s;
+  }
+  if (TRAIN) {
+    const int mi = wave & 1, nj = wave >> 1;
+#pragma unroll
+    for (int t = 0; t < NPT; t++) {
+      const int f0 = f_chunk0 + t * FT;
+      if (f0 >= g.F) break;
+      if (nj < NTK) {
+        int k = nj * 32 + r;
+        if (k < g.K) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            int f = f0 + mi * 32 + acc_row(e, lane);
+            if (f < g.F) g.dW[(long)f * g.lddw + k] = accW[t][e];
+          }
+        }
+      }
+      // per-feature sums: lanes (r, hq=0/1) of waves (ti=0/1, tj) hold partials of feature tj*32+r
+      float v0 = db_acc[t] + __shfl_xor(db_acc[t], 32, 64);
+      float v1 = dfs_acc[t] + __shfl_xor(dfs_acc[t], 32, 64);
+      float v2 = dth_acc[t] + __shfl_xor(dth_acc[t], 32, 64);
+      if (hq == 0) {
+        cred[((ti * NPT + t) * 3 + 0) * FT + tj * 32 + r] = v0;
+        cred[((ti * NPT + t) * 3 + 1) * FT + tj * 32 + r] = v1;
+        cred[((ti * NPT + t) * 3 + 2) * FT + tj * 32 + r] = v2;
+      }
+    }
+    __syncthreads();
+    static_assert(2 * NPT * 3 * FT <= CB * FT, "cred must fit inside the label tile it aliases");
+    for (int idx = tid; idx < NPT * FT; idx += 256) {
+      int t = idx / FT, fl = idx % FT;
+      int f = f_chunk0 + t * FT + fl;
+      if (f < g.F) {
+        float v0 = cred[((0 * NPT + t) * 3 + 0) * FT + fl] + cred[((1 * NPT + t) * 3 + 0) * FT + fl];
+        float v1 = cred[((0 * NPT + t) * 3 + 1) * FT + fl] + cred[((1 * NPT + t) * 3 + 1) * FT + fl];
+        float v2 = cred[((0 * NPT + t) * 3 + 2) * FT + fl] + cred[((1 * NPT + t) * 3 + 2) * FT + fl];
+        if (g.db) g.db[f] = v0;
+        if (g.dfs) g.dfs[f] = v1;
+        if (g.dtheta) g.dtheta[f] = v2;
+      }
+    }
+  }
+}
+
+
+#define DEC_NPT 4
+
+template <int NS, int KP>
+static size_t dec_smem() {
+  size_t bf = (size_t)NS * ((size_t)CB * (KP + 8) * 2 + (size_t)KP * LDZ * 2 + (size_t)CB * LDZ * 2);
+  return bf * sizeof(__bf16) + sizeof(float) * (CB * FT + 3 * CB + 4 * CB);
+}
+
+template <int NS, int KP, int MODE>
+static int dec_launch(const DecArgs& g, int grid, hipStream_t stream) {
+  static bool attr_done = false;
+  size_t smem = dec_smem<NS, KP>();
+  if (!attr_done) {
+    SCP_HIP(hipFuncSetAttribute((const void*)dec_kernel<NS, KP, DEC_NPT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((dec_kernel<NS, KP, DEC_NPT, MODE>), dim3(grid), dim3(256), smem, stream, g);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+// one translation unit per (NS, family) keeps the build parallel
+template <int NS, int MODE>
+static int dec_run_mode(const DecArgs& g, int kp, int grid, hipStream_t stream) {
+  if (kp == 16) return dec_launch<NS, 16, MODE>(g, grid, stream);
+  if (kp == 48) return dec_launch<NS, 48, MODE>(g, grid, stream);
+  if constexpr (NS == 1) {
+    if (kp == 64) return dec_launch<NS, 64, MODE>(g, grid, stream);
+  }
+  scp_set_error("decoder: unsupported (ns=%d, KP=%d)", NS, kp);
+  return SCP_ERR_SHAPE;
+}

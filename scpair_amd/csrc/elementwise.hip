@@ -1,0 +1,237 @@
+// Small fused elementwise / reduction kernels of the hot path:
+//   masked MSE (loss.py:22-27), reparameterisation + KL (pairedVAE.py:51-58, utils.py:186),
+//   decoder inference heads for predict() (model.py:558-591), deterministic partial-sum finalisers.
+#include "common.h"
+#include "scpair_hip.h"
+
+// ---- deterministic reduction of per-block double partials ---------------------------------------
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ part, int n, int ncomp,
+                                                              double* __restrict__ out) {
+  __shared__ double red[8];
+  int comp = blockIdx.x;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[(long)i * ncomp + comp];
+  s = block_sum_d(s, red);
+  if (threadIdx.x == 0) out[comp] = s;
+}
+
+int scp_reduce_partials(const double* part, int n, int ncomp, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ncomp), dim3(256), 0, stream, part, n, ncomp, out);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+// ---- masked MSE ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ mu,
+                                                      long ldm, int rows, int cols, double* __restrict__ part) {
+  __shared__ double red[8];
+  long n = (long)rows * cols;
+  double s = 0.0, cnt = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    long r = i / cols;
+    int c = (int)(i % cols);
+    float xv = x[r * ldx + c];
+    if (xv == xv) {
+      float d = mu[r * ldm + c] - xv;
+      s += (double)(d * d);
+      cnt += 1.0;
+    }
+  }
+  s = block_sum_d(s, red);
+  cnt = block_sum_d(cnt, red);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = s;
+    part[2 * blockIdx.x + 1] = cnt;
+  }
+}
+
+__global__ void mse_finish_kernel(const double* __restrict__ sums, float* __restrict__ loss_cnt) {
+  loss_cnt[0] = (float)(sums[0] / sums[1]);
+  loss_cnt[1] = (float)sums[1];
+}
+
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ mu,
+                                                      long ldm, int rows, int cols, const float* __restrict__ loss_cnt,
+                                                      const float* __restrict__ gout, float* __restrict__ dmu, long ldd) {
+  long n = (long)rows * cols;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  long r = i / cols;
+  int c = (int)(i % cols);
+  float xv = x[r * ldx + c];
+  float sc = 2.f * (gout ? gout[0] : 1.f) / loss_cnt[1];
+  dmu[r * ldd + c] = (xv == xv) ? sc * (mu[r * ldm + c] - xv) : 0.f;
+}
+
+// loss_cnt[0] = mean((mu-x)^2 over non-NaN x), loss_cnt[1] = count.  ws: >= 2*256+2 doubles
+extern "C" int scp_mse_masked_fwd(const float* x, long ldx, const float* mu, long ldm, int rows, int cols,
+                                  float* loss_cnt, double* ws, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SCP_CHECK(x && mu && loss_cnt && ws && rows > 0 && cols > 0, SCP_ERR_ARG, "scp_mse_masked_fwd: bad argument");
+  long n = (long)rows * cols;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, ldx, mu, ldm, rows, cols, ws);
+  SCP_LAUNCH_CHECK();
+  int rc = scp_reduce_partials(ws, grid, 2, ws + 512, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(1), 0, stream, ws + 512, loss_cnt);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_mse_masked_bwd(const float* x, long ldx, const float* mu, long ldm, int rows, int cols,
+                                  const float* loss_cnt, const float* gout, float* dmu, long ldd, void* stream_) {
+  SCP_CHECK(x && mu && loss_cnt && dmu && rows > 0 && cols > 0, SCP_ERR_ARG, "scp_mse_masked_bwd: bad argument");
+  long n = (long)rows * cols;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, ldx, mu,
+                     ldm, rows, cols, loss_cnt, gout, dmu, ldd);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+// ---- reparameterisation + KL ------------------------------------------------------------------------
+// sigma = softplus(s_raw) + 1e-7 ; z = mu + eps*sigma ; kl = mean(-log sigma + (sigma^2 + mu^2)/2 - 1/2)
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sraw,
+                                                             const float* __restrict__ eps, long n,
+                                                             float* __restrict__ sigma, float* __restrict__ z,
+                                                             double* __restrict__ part) {
+  __shared__ double red[8];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float m = mu[i];
+    float sg = softplus_t(sraw[i]) + 1e-7f;
+    sigma[i] = sg;
+    z[i] = m + eps[i] * sg;
+    s += (double)(-logf(sg) + 0.5f * (sg * sg + m * m) - 0.5f);
+  }
+  s = block_sum_d(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void kl_finish_kernel(const double* __restrict__ sums, long n, float* __restrict__ kl) {
+  kl[0] = (float)(sums[0] / (double)n);
+}
+
+// dmu = dz + c*mu ; dsraw = (dz*eps + c*(sigma - 1/sigma)) * sigmoid(sraw) [threshold branch: 1], c = gkl/n
+// dsigma_extra: optional extra gradient wrt sigma (the reference returns sigma; nothing consumes it)
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sraw,
+                                                             const float* __restrict__ eps,
+                                                             const float* __restrict__ sigma,
+                                                             const float* __restrict__ dz, const float* __restrict__ dmu_in,
+                                                             const float* __restrict__ gkl, long n,
+                                                             float* __restrict__ dmu, float* __restrict__ dsraw) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float c = (gkl ? gkl[0] : 0.f) / (float)n;
+  float sg = sigma[i];
+  float g = dz ? dz[i] : 0.f;
+  dmu[i] = g + c * mu[i] + (dmu_in ? dmu_in[i] : 0.f);
+  float ds = g * eps[i] + c * (sg - 1.f / sg);
+  float sr = sraw[i];
+  float dsp = sr > 20.f ? 1.f : sigmoidf_(sr);
+  dsraw[i] = ds * dsp;
+}
+
+extern "C" int scp_reparam_kl_fwd(const float* mu, const float* sraw, const float* eps, long n, float* sigma, float* z,
+                                  float* kl, double* ws, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SCP_CHECK(mu && sraw && eps && sigma && z && kl && ws && n > 0, SCP_ERR_ARG, "scp_reparam_kl_fwd: bad argument");
+  int grid = (int)((n + 255) / 256);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid), dim3(256), 0, stream, mu, sraw, eps, n, sigma, z, ws);
+  SCP_LAUNCH_CHECK();
+  int rc = scp_reduce_partials(ws, grid, 1, ws + 512, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(1), 0, stream, ws + 512, n, kl);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_reparam_kl_bwd(const float* mu, const float* sraw, const float* eps, const float* sigma,
+                                  const float* dz, const float* dmu_in, const float* gkl, long n, float* dmu,
+                                  float* dsraw, void* stream_) {
+  SCP_CHECK(mu && sraw && eps && sigma && dmu && dsraw && n > 0, SCP_ERR_ARG, "scp_reparam_kl_bwd: bad argument");
+  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, mu,
+                     sraw, eps, sigma, dz, dmu_in, gkl, n, dmu, dsraw);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+// ---- decoder inference heads (predict / reconstructions) ---------------------------------------------
+// Bernoulli: out = sigmoid(z) [* sigmoid(l_row)] [* sigmoid(fs_col)]   (model.py:173-189), in place allowed
+__global__ __launch_bounds__(256) void ber_prob_kernel(const float* __restrict__ z, long ldz, int rows, int cols,
+                                                       const float* __restrict__ lrow, int lrow_n,
+                                                       const float* __restrict__ fs, float* __restrict__ out, long ldo) {
+  long n = (long)rows * cols;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  long r = i / cols;
+  int c = (int)(i % cols);
+  float p = sigmoidf_(z[r * ldz + c]);
+  if (lrow) p *= sigmoidf_(lrow[lrow_n == 1 ? 0 : r]);
+  if (fs) p *= sigmoidf_(fs[c]);
+  out[r * ldo + c] = p;
+}
+
+extern "C" int scp_ber_prob(const float* z, long ldz, int rows, int cols, const float* lrow, int lrow_n, const float* fs,
+                            float* out, long ldo, void* stream_) {
+  SCP_CHECK(z && out && rows > 0 && cols > 0, SCP_ERR_ARG, "scp_ber_prob: bad argument");
+  long n = (long)rows * cols;
+  hipLaunchKernelGGL(ber_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, z, ldz, rows,
+                     cols, lrow, lrow_n, fs, out, ldo);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+// Raw: a = relu(z) ; scale = softmax_row(a [* sigmoid(fs)]) ; optional theta = exp(a) ; one block per row
+__global__ __launch_bounds__(256) void relu_softmax_kernel(const float* __restrict__ z, long ldz, int cols,
+                                                           const float* __restrict__ fs, int apply_relu,
+                                                           float* __restrict__ scale, long lds_,
+                                                           float* __restrict__ theta, long ldt) {
+  __shared__ float red[8];
+  __shared__ float bc;
+  long r = blockIdx.x;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float a = z[r * ldz + c];
+    if (apply_relu) a = fmaxf(a, 0.f);
+    if (fs) a *= sigmoidf_(fs[c]);
+    m = fmaxf(m, a);
+  }
+  m = wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  m = bc;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float a = z[r * ldz + c];
+    if (apply_relu) a = fmaxf(a, 0.f);
+    if (fs) a *= sigmoidf_(fs[c]);
+    s += expf(a - m);
+  }
+  s = block_sum(s, red);
+  __syncthreads();
+  if (threadIdx.x == 0) bc = s;
+  __syncthreads();
+  float inv = 1.f / bc;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float a0 = z[r * ldz + c];
+    if (apply_relu) a0 = fmaxf(a0, 0.f);
+    float a = fs ? a0 * sigmoidf_(fs[c]) : a0;
+    scale[r * lds_ + c] = expf(a - m) * inv;
+    if (theta) theta[r * ldt + c] = expf(a0);
+  }
+}
+
+extern "C" int scp_relu_softmax_rows(const float* z, long ldz, int rows, int cols, const float* fs, int apply_relu,
+                                     float* scale, long lds_, float* theta, long ldt, void* stream_) {
+  SCP_CHECK(z && scale && rows > 0 && cols > 0, SCP_ERR_ARG, "scp_relu_softmax_rows: bad argument");
+  hipLaunchKernelGGL(relu_softmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream_, z, ldz, cols, fs, apply_relu,
+                     scale, lds_, theta, ldt);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}

@@ -1,0 +1,460 @@
+"""torch.autograd.Function wrappers over the C-ABI HIP kernels (include/scpair_hip.h).
+
+Every op here runs on the GPU through libscpair_hip.so; nothing falls back to eager torch math.
+torch supplies device memory, the current stream and the autograd tape only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from .sparse import BatchTiles
+
+_cfg = {"ns": 3, "seed_ctr": 0}
+
+
+def set_precision(mode: str):
+    """'fp32'  -> every fp32 MFMA operand is split into 3 bf16 terms (fp32-equivalent products)
+       'bf16'  -> operands rounded to bf16 once (fp32 accumulate, fp32 master weights)"""
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    _cfg["ns"] = 3 if mode == "fp32" else 1
+
+
+def get_precision() -> str:
+    return "fp32" if _cfg["ns"] == 3 else "bf16"
+
+
+def _ns():
+    return _cfg["ns"]
+
+
+def next_seed() -> int:
+    _cfg["seed_ctr"] += 1
+    return ((torch.initial_seed() & 0xFFFFFFFF) << 24) + _cfg["seed_ctr"]
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launchers
+# ------------------------------------------------------------------------------------------------
+def gemm_nt(M, N, K, A, a_sr, a_sk, B, b_sr, b_sk, Cout, ldc, bias=None, accumulate=False, nsplit=1, ns=None,
+            a_off=0, b_off=0, c_off=0):
+    L = _lib.lib()
+    _lib.check(L.scp_gemm_nt(M, N, K, A.data_ptr() + 4 * a_off, a_sr, a_sk, B.data_ptr() + 4 * b_off, b_sr, b_sk,
+                             Cout.data_ptr() + 4 * c_off, ldc, _lib.ptr(bias), int(accumulate), nsplit,
+                             ns or _ns(), _lib.stream()), "scp_gemm_nt")
+
+
+def colsum(X, rows, cols, ld=None):
+    L = _lib.lib()
+    out = _empty((cols,), X)
+    ws = _empty((32 * cols,), X)
+    _lib.check(L.scp_colsum(X.data_ptr(), ld or cols, rows, cols, out.data_ptr(), ws.data_ptr(), _lib.stream()),
+               "scp_colsum")
+    return out
+
+
+def _pick_split(M, N, K):
+    """Split-K factor so that a tall-K GEMM still fills ~2 waves of 256 CUs."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    want = max(1, 512 // max(tiles, 1))
+    ksteps = (K + 63) // 64
+    return max(1, min(want, ksteps // 4 if ksteps >= 8 else 1, 32))
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear (dense):  y = x W^T + b
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        _lib.require_cuda(x, W, b)
+        x = _f32c(x)
+        Wc = _f32c(W)
+        M, K = x.shape
+        N = Wc.shape[0]
+        y = _empty((M, N), x)
+        gemm_nt(M, N, K, x, K, 1, Wc, K, 1, y, N, bias=_f32c(b))
+        ctx.save_for_backward(x, Wc)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _f32c(dy)
+        M, K = x.shape
+        N = W.shape[0]
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((M, K), x)
+            # dx[m][j] = sum_n dy[m][n] W[n][j]
+            gemm_nt(M, K, N, dy, N, 1, W, 1, K, dx, K)
+        if ctx.needs_input_grad[1]:
+            dW = _empty((N, K), x)
+            # dW[n][j] = sum_m dy[m][n] x[m][j]
+            gemm_nt(N, K, M, dy, 1, N, x, 1, K, dW, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, M, N)
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    return LinearFn.apply(x, W, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# FCNN layer: Linear -> [LayerNorm] -> LeakyReLU(slope) -> Dropout(p), dense or sparse input
+# (utils.py:54-64; BatchNorm, when enabled, is applied by the caller between act and dropout)
+# ------------------------------------------------------------------------------------------------
+class FcnnLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cov, W, b, gamma, beta, slope, p_drop, seed, eps):
+        """x: dense [B, F] tensor or BatchTiles; cov: dense [B, C] or None; W: [H, F + C]."""
+        L = _lib.lib()
+        sparse = isinstance(x, BatchTiles)
+        Wc = _f32c(W)
+        _lib.require_cuda(Wc, cov, None if sparse else x)
+        H, Ftot = Wc.shape
+        Bn, F = x.shape
+        C_ = 0 if cov is None else cov.shape[1]
+        if F + C_ != Ftot:
+            raise ValueError(f"FCNN layer: weight expects {Ftot} inputs, got {F} (+{C_} covariates)")
+        ns = _ns()
+        dev = Wc.device
+        nsplit = _pick_split(Bn, H, F)
+        nsplit = L.scp_gemm_split_count(F, nsplit)
+        nslab = nsplit + (1 if C_ else 0)
+        slabs = torch.empty((nslab, Bn, H), dtype=torch.float32, device=dev)
+        if sparse:
+            _lib.check(L.scp_spmm_fwd(Bn, H, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), Wc.data_ptr(),
+                                      Ftot, slabs.data_ptr(), H, None, nsplit, ns, _lib.stream()), "scp_spmm_fwd")
+            xs = None
+        else:
+            xs = _f32c(x)
+            gemm_nt(Bn, H, F, xs, F, 1, Wc, Ftot, 1, slabs, H, nsplit=nsplit, ns=ns)
+        covc = None
+        if C_:
+            covc = _f32c(cov)
+            gemm_nt(Bn, H, C_, covc, C_, 1, Wc, Ftot, 1, slabs, H, ns=ns, b_off=F, c_off=nsplit * Bn * H)
+        out = torch.empty((Bn, H), dtype=torch.float32, device=dev)
+        xhat = torch.empty((Bn, H), dtype=torch.float32, device=dev)
+        rstd = torch.empty((Bn,), dtype=torch.float32, device=dev)
+        g_, b_ = _f32c(gamma), _f32c(beta)
+        _lib.check(L.scp_ln_act_fwd(slabs.data_ptr(), H, Bn * H, nslab, _lib.ptr(_f32c(b)), _lib.ptr(g_), _lib.ptr(b_),
+                                    Bn, H, eps, slope, p_drop, seed, xhat.data_ptr(), H, rstd.data_ptr(),
+                                    out.data_ptr(), H, _lib.stream()), "scp_ln_act_fwd")
+        ctx.sparse = sparse
+        ctx.tiles = x if sparse else None
+        ctx.save_for_backward(xs, covc, Wc, g_, b_, xhat, rstd)
+        ctx.cfg = (slope, p_drop, seed, Bn, H, F, C_, ns, b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        xs, cov, W, gamma, beta, xhat, rstd = ctx.saved_tensors
+        slope, p_drop, seed, Bn, H, F, C_, ns, has_bias = ctx.cfg
+        dout = _f32c(dout)
+        dev = W.device
+        Ftot = F + C_
+        dY = torch.empty((Bn, H), dtype=torch.float32, device=dev)
+        dgamma = torch.empty(H, dtype=torch.float32, device=dev) if gamma is not None else None
+        dbeta = torch.empty(H, dtype=torch.float32, device=dev) if gamma is not None else None
+        dbias = torch.empty(H, dtype=torch.float32, device=dev) if has_bias else None
+        ws = torch.empty(L.scp_ln_act_bwd_grid(Bn) * 3 * H, dtype=torch.float32, device=dev)
+        _lib.check(L.scp_ln_act_bwd(dout.data_ptr(), H, xhat.data_ptr(), H, rstd.data_ptr(), _lib.ptr(gamma),
+                                    _lib.ptr(beta), Bn, H, slope, p_drop, seed, dY.data_ptr(), H, _lib.ptr(dgamma),
+                                    _lib.ptr(dbeta), _lib.ptr(dbias), ws.data_ptr(), _lib.stream()), "scp_ln_act_bwd")
+        dx = dW = None
+        if ctx.needs_input_grad[2]:
+            dW = torch.empty((H, Ftot), dtype=torch.float32, device=dev)
+            if ctx.sparse:
+                t = ctx.tiles
+                _lib.check(L.scp_spmm_dw(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), dY.data_ptr(), H,
+                                         dW.data_ptr(), Ftot, ns, _lib.stream()), "scp_spmm_dw")
+            else:
+                gemm_nt(H, F, Bn, dY, 1, H, xs, 1, F, dW, Ftot, ns=ns)
+            if C_:
+                gemm_nt(H, C_, Bn, dY, 1, H, cov, 1, C_, dW, Ftot, ns=ns, c_off=F)
+        if (not ctx.sparse) and ctx.needs_input_grad[0]:
+            dx = torch.empty((Bn, F), dtype=torch.float32, device=dev)
+            gemm_nt(Bn, F, H, dY, H, 1, W, 1, Ftot, dx, F, ns=ns)
+        return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None
+
+
+def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
+    return FcnnLayerFn.apply(x, cov, W, b, gamma, beta, float(slope), float(p_drop), int(seed), float(eps))
+
+
+# ------------------------------------------------------------------------------------------------
+# fused decoders + losses
+# ------------------------------------------------------------------------------------------------
+def _dec_ws(B, F, K, dev):
+    L = _lib.lib()
+    ws_f = torch.empty(L.scp_dec_ws_floats(B, F, K), dtype=torch.float32, device=dev)
+    ws_d = torch.empty(L.scp_dec_ws_doubles(F), dtype=torch.float64, device=dev)
+    return ws_f, ws_d
+
+
+class BerDecoderLossFn(torch.autograd.Function):
+    """loss = binarized_loss(y, sigmoid(h W^T + b) [* sigmoid(lrow)] [* sigmoid(fs)])  (model.py:164-190, loss.py:36-41)
+    with dW, db, dh, dlrow, dfs produced by the same kernel pass."""
+
+    @staticmethod
+    def forward(ctx, h, W, b, fs, lrow, tiles):
+        L = _lib.lib()
+        h, Wc, bc = _f32c(h), _f32c(W), _f32c(b)
+        _lib.require_cuda(h, Wc, bc)
+        fsc = _f32c(fs)
+        lr = None if lrow is None else _f32c(lrow).reshape(-1)
+        Bn, K = h.shape
+        F = Wc.shape[0]
+        if tiles.shape != (Bn, F):
+            raise ValueError(f"label tiles are {tiles.shape}, decoder output is {(Bn, F)}")
+        lrow_n = 0 if lr is None else lr.numel()
+        dev = h.device
+        train = any(ctx.needs_input_grad[:5])
+        ws_f, ws_d = _dec_ws(Bn, F, K, dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dW = db = dh = dfs = dl = None
+        if train:
+            dW = torch.empty((F, K), dtype=torch.float32, device=dev)
+            db = torch.empty(F, dtype=torch.float32, device=dev)
+            dh = torch.empty((Bn, K), dtype=torch.float32, device=dev)
+            dfs = torch.empty(F, dtype=torch.float32, device=dev) if fsc is not None else None
+            dl = torch.empty(Bn, dtype=torch.float32, device=dev) if lrow_n == Bn else None
+        _lib.check(L.scp_ber_dec_bce(int(train), Bn, F, K, h.data_ptr(), K, Wc.data_ptr(), K, bc.data_ptr(),
+                                     _lib.ptr(fsc), _lib.ptr(lr), lrow_n, _lib.ptr(tiles.ptr), _lib.ptr(tiles.key),
+                                     _lib.ptr(tiles.val), _lib.ptr(tiles.nnan), None, loss.data_ptr(), _lib.ptr(dW), K,
+                                     _lib.ptr(db), _lib.ptr(dfs), _lib.ptr(dh), K, _lib.ptr(dl), ws_f.data_ptr(),
+                                     ws_d.data_ptr(), _ns(), _lib.stream()), "scp_ber_dec_bce")
+        ctx.grads = (dh, dW, db, dfs, dl)
+        ctx.lshape = None if lrow is None else lrow.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dh, dW, db, dfs, dl = ctx.grads
+        ctx.grads = None
+        sc = lambda t: None if t is None else t * g
+        dl_ = None if dl is None else (dl * g).reshape(ctx.lshape)
+        return sc(dh), sc(dW), sc(db), sc(dfs), dl_, None
+
+
+def ber_decoder_loss(h, W, b, fs, lrow, tiles):
+    return BerDecoderLossFn.apply(h, W, b, fs, lrow, tiles)
+
+
+class NbDecoderLossFn(torch.autograd.Function):
+    """loss = raw_loss('nb') of Output_Module_Raw (model.py:229-259, loss.py:46-48), fused with its backward.
+    lib_L: per-cell library size (sample_factor) or exp(leaky_relu(latent_lib)); lat: latent_lib or None."""
+
+    @staticmethod
+    def forward(ctx, h, W, b, fs, theta_param, lib_L, lat, tiles):
+        L = _lib.lib()
+        h, Wc, bc = _f32c(h), _f32c(W), _f32c(b)
+        _lib.require_cuda(h, Wc, bc)
+        fsc, thp = _f32c(fs), _f32c(theta_param)
+        Lr = _f32c(lib_L).reshape(-1)
+        latc = None if lat is None else _f32c(lat).reshape(-1)
+        Bn, K = h.shape
+        F = Wc.shape[0]
+        if tiles.shape != (Bn, F):
+            raise ValueError(f"label tiles are {tiles.shape}, decoder output is {(Bn, F)}")
+        if Lr.numel() != Bn:
+            raise ValueError("library size must have one entry per cell")
+        dev = h.device
+        train = any(ctx.needs_input_grad[:7])
+        ws_f, ws_d = _dec_ws(Bn, F, K, dev)
+        rowbuf = torch.empty(2 * Bn, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dW = db = dh = dfs = dth = dlat = None
+        if train:
+            dW = torch.empty((F, K), dtype=torch.float32, device=dev)
+            db = torch.empty(F, dtype=torch.float32, device=dev)
+            dh = torch.empty((Bn, K), dtype=torch.float32, device=dev)
+            dfs = torch.empty(F, dtype=torch.float32, device=dev) if fsc is not None else None
+            dth = torch.empty(F, dtype=torch.float32, device=dev) if thp is not None else None
+            dlat = torch.empty(Bn, dtype=torch.float32, device=dev) if latc is not None else None
+        _lib.check(L.scp_nb_dec_ll(int(train), Bn, F, K, h.data_ptr(), K, Wc.data_ptr(), K, bc.data_ptr(), _lib.ptr(fsc),
+                                   _lib.ptr(thp), Lr.data_ptr(), _lib.ptr(latc), _lib.ptr(tiles.ptr), _lib.ptr(tiles.key),
+                                   _lib.ptr(tiles.val), None, loss.data_ptr(), _lib.ptr(dW), K, _lib.ptr(db),
+                                   _lib.ptr(dfs), _lib.ptr(dth), _lib.ptr(dh), K, _lib.ptr(dlat), rowbuf.data_ptr(),
+                                   ws_f.data_ptr(), ws_d.data_ptr(), _ns(), _lib.stream()), "scp_nb_dec_ll")
+        ctx.grads = (dh, dW, db, dfs, dth, dlat)
+        ctx.latshape = None if lat is None else lat.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dh, dW, db, dfs, dth, dlat = ctx.grads
+        ctx.grads = None
+        sc = lambda t: None if t is None else t * g
+        dlat_ = None if dlat is None else (dlat * g).reshape(ctx.latshape)
+        return sc(dh), sc(dW), sc(db), sc(dfs), sc(dth), None, dlat_, None
+
+
+def nb_decoder_loss(h, W, b, fs, theta_param, lib_L, lat, tiles):
+    return NbDecoderLossFn.apply(h, W, b, fs, theta_param, lib_L, lat, tiles)
+
+
+# ------------------------------------------------------------------------------------------------
+# masked MSE, reparameterisation + KL
+# ------------------------------------------------------------------------------------------------
+class MseMaskedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mu):
+        L = _lib.lib()
+        x, mu = _f32c(x), _f32c(mu)
+        _lib.require_cuda(x, mu)
+        if x.shape != mu.shape:
+            raise ValueError("scaled_loss: shape mismatch")
+        rows = x.shape[0] if x.ndim > 1 else 1
+        cols = x.numel() // rows
+        lc = torch.empty(2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(520, dtype=torch.float64, device=x.device)
+        _lib.check(L.scp_mse_masked_fwd(x.data_ptr(), cols, mu.data_ptr(), cols, rows, cols, lc.data_ptr(),
+                                        ws.data_ptr(), _lib.stream()), "scp_mse_masked_fwd")
+        ctx.save_for_backward(x, mu, lc)
+        ctx.rc = (rows, cols)
+        return lc[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x, mu, lc = ctx.saved_tensors
+        rows, cols = ctx.rc
+        g = _f32c(g).reshape(1)
+        dmu = torch.empty_like(mu)
+        _lib.check(L.scp_mse_masked_bwd(x.data_ptr(), cols, mu.data_ptr(), cols, rows, cols, lc.data_ptr(),
+                                        g.data_ptr(), dmu.data_ptr(), cols, _lib.stream()), "scp_mse_masked_bwd")
+        return None, dmu
+
+
+def mse_masked(x, mu):
+    return MseMaskedFn.apply(x, mu)
+
+
+class ReparamKlFn(torch.autograd.Function):
+    """(mu, s_raw, eps) -> sigma = softplus(s_raw)+1e-7, z = mu + eps*sigma, kl = mean KL(N(mu,sigma)||N(0,1))."""
+
+    @staticmethod
+    def forward(ctx, mu, sraw, eps):
+        L = _lib.lib()
+        mu, sraw, eps = _f32c(mu), _f32c(sraw), _f32c(eps)
+        _lib.require_cuda(mu, sraw, eps)
+        n = mu.numel()
+        sigma, z = torch.empty_like(mu), torch.empty_like(mu)
+        kl = torch.empty(1, dtype=torch.float32, device=mu.device)
+        ws = torch.empty(520, dtype=torch.float64, device=mu.device)
+        _lib.check(L.scp_reparam_kl_fwd(mu.data_ptr(), sraw.data_ptr(), eps.data_ptr(), n, sigma.data_ptr(), z.data_ptr(),
+                                        kl.data_ptr(), ws.data_ptr(), _lib.stream()), "scp_reparam_kl_fwd")
+        ctx.save_for_backward(mu, sraw, eps, sigma)
+        ctx.mark_non_differentiable(sigma)
+        return sigma, z, kl.reshape(())
+
+    @staticmethod
+    def backward(ctx, _dsigma, dz, dkl):
+        L = _lib.lib()
+        mu, sraw, eps, sigma = ctx.saved_tensors
+        n = mu.numel()
+        dzc = None if dz is None else _f32c(dz)
+        gk = None if dkl is None else _f32c(dkl).reshape(1)
+        dmu, dsraw = torch.empty_like(mu), torch.empty_like(mu)
+        _lib.check(L.scp_reparam_kl_bwd(mu.data_ptr(), sraw.data_ptr(), eps.data_ptr(), sigma.data_ptr(), _lib.ptr(dzc),
+                                        None, _lib.ptr(gk), n, dmu.data_ptr(), dsraw.data_ptr(), _lib.stream()),
+                   "scp_reparam_kl_bwd")
+        return dmu, dsraw, None
+
+
+def reparam_kl(mu, sraw, eps):
+    return ReparamKlFn.apply(mu, sraw, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# inference heads
+# ------------------------------------------------------------------------------------------------
+def ber_prob(z, lrow=None, fs=None):
+    L = _lib.lib()
+    z = _f32c(z)
+    rows, cols = z.shape
+    out = torch.empty_like(z)
+    lr = None if lrow is None else _f32c(lrow).reshape(-1)
+    _lib.check(L.scp_ber_prob(z.data_ptr(), cols, rows, cols, _lib.ptr(lr), 0 if lr is None else lr.numel(),
+                              _lib.ptr(_f32c(fs)), out.data_ptr(), cols, _lib.stream()), "scp_ber_prob")
+    return out
+
+
+def relu_softmax_rows(z, fs=None, apply_relu=True, want_theta=False):
+    L = _lib.lib()
+    z = _f32c(z)
+    rows, cols = z.shape
+    scale = torch.empty_like(z)
+    theta = torch.empty_like(z) if want_theta else None
+    _lib.check(L.scp_relu_softmax_rows(z.data_ptr(), cols, rows, cols, _lib.ptr(_f32c(fs)), int(apply_relu),
+                                       scale.data_ptr(), cols, _lib.ptr(theta), cols, _lib.stream()),
+               "scp_relu_softmax_rows")
+    return scale, theta
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+class FusedAdamW(torch.optim.Optimizer):
+    """Drop-in for torch.optim.AdamW as the reference configures it (model.py:698-701): same param_groups
+    / state layout ('step', 'exp_avg', 'exp_avg_sq'), one fused multi-tensor HIP launch per step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        by_hyper = {}
+        keep = []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _lib.require_cuda(p)
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdamW needs contiguous parameters")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                t = st["step"]
+                d = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                    p.numel(), group["lr"], group["weight_decay"], 1 - b1 ** t, 1 - b2 ** t, grad_scale)
+                by_hyper.setdefault((b1, b2, group["eps"]), []).append(d)
+                keep.append(g)
+        for (b1, b2, eps), descs in by_hyper.items():
+            arr = (_lib.AdamTensor * len(descs))(*descs)
+            _lib.check(L.scp_adamw_multi(arr, len(descs), b1, b2, eps, _lib.stream()), "scp_adamw_multi")
+        return loss

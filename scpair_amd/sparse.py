@@ -1,0 +1,134 @@
+"""Device-resident CSR count matrices and per-minibatch tile lists.
+
+Replaces the reference's dense CPU tensors + LazyGPUDataset/DataLoader batch gather
+(model.py:26-38, 492-510, 704-717): a split (train/val/test) of one modality stays in HBM as CSR for
+the whole run, and a minibatch is just a vector of its row ids.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class DeviceCSR:
+    """CSR cell x feature matrix in GPU memory (int64 indptr, int32 indices, fp32 values or implicit ones)."""
+
+    def __init__(self, indptr, indices, values, shape, device):
+        self.shape = (int(shape[0]), int(shape[1]))
+        ip = np.ascontiguousarray(np.asarray(indptr, dtype=np.int64))
+        self.indptr_host = ip
+        self.device = torch.device(device)
+        self.indptr = torch.from_numpy(ip).to(self.device)
+        self.indices = torch.as_tensor(np.ascontiguousarray(np.asarray(indices, dtype=np.int32))).to(self.device)
+        self.values = None if values is None else torch.as_tensor(
+            np.ascontiguousarray(np.asarray(values, dtype=np.float32))).to(self.device)
+        if ip.shape[0] != self.shape[0] + 1:
+            raise ValueError("indptr length does not match the row count")
+        if self.shape[1] >= (1 << 25):
+            raise ValueError("more than 2^25 features are not supported by the tile-list key format")
+
+    @classmethod
+    def from_scipy(cls, m, device="cuda", binary=False):
+        """Canonical CSR required (duplicates summed, indices sorted): scipy's .sum_duplicates() does both."""
+        import scipy.sparse as sp
+        m = sp.csr_matrix(m)
+        if not m.has_canonical_format:
+            m = m.copy()
+            m.sum_duplicates()
+        vals = None if binary else m.data
+        return cls(m.indptr, m.indices, vals, m.shape, device)
+
+    @classmethod
+    def from_dense(cls, x, device="cuda"):
+        """Dense tensor / array -> CSR.  NaN entries (missing labels, loss.py:24,38) are kept as explicit entries."""
+        import scipy.sparse as sp
+        a = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        mask = (a != 0) | np.isnan(a)
+        rows, cols = np.nonzero(mask)
+        m = sp.csr_matrix((a[rows, cols].astype(np.float32), (rows, cols)), shape=a.shape)
+        return cls(m.indptr, m.indices, m.data, m.shape, device)
+
+    @property
+    def n_rows(self):
+        return self.shape[0]
+
+    @property
+    def n_cols(self):
+        return self.shape[1]
+
+    def nnz_of(self, rows_host: np.ndarray) -> int:
+        ip = self.indptr_host
+        return int((ip[rows_host + 1] - ip[rows_host]).sum())
+
+    def to_dense(self, rows=None):
+        """Dense fp32 copy (tests / small inference only)."""
+        ip = self.indptr_host
+        n = self.shape[0]
+        idx = self.indices.cpu().numpy()
+        val = np.ones(idx.shape[0], np.float32) if self.values is None else self.values.cpu().numpy()
+        out = np.zeros(self.shape, np.float32)
+        r = np.repeat(np.arange(n), np.diff(ip))
+        out[r, idx] = val
+        if rows is not None:
+            out = out[np.asarray(rows)]
+        return torch.from_numpy(out)
+
+
+class BatchTiles:
+    """Tile list of one minibatch of one modality (built on the GPU by scp_tiles_build).
+
+    ptr : int32 [ncb*F + 2]   entries of (cell block cb, feature f) are key/val[ptr[cb*F+f] : ptr[cb*F+f+1]]
+    key : int32 [nnz]         (feature << 6) | cell-in-block
+    val : fp32  [nnz] or None (implicit ones)
+    lib : fp32  [B]           row sums (library size, model.py:509-510)
+    nnan: int32 [1]           number of NaN values (missing labels)
+    """
+
+    def __init__(self, csr: DeviceCSR, rows, want_lib=True, rows_host=None):
+        L = _lib.lib()
+        dev = csr.device
+        if isinstance(rows, torch.Tensor):
+            rows_dev = rows.to(device=dev, dtype=torch.int64).contiguous()
+            if rows_host is None:
+                rows_host = rows.detach().cpu().numpy()
+        else:
+            rows_host = np.asarray(rows, dtype=np.int64)
+            rows_dev = torch.from_numpy(rows_host).to(dev)
+        rows_host = np.asarray(rows_host, dtype=np.int64)
+        self.B = int(rows_host.shape[0])
+        self.F = csr.n_cols
+        if self.B == 0:
+            raise ValueError("empty minibatch")
+        if rows_host.min() < 0 or rows_host.max() >= csr.n_rows:
+            raise IndexError("minibatch row id out of range")
+        self.nnz = csr.nnz_of(rows_host)
+        self.rows = rows_dev
+        self.ptr = torch.empty(L.scp_tiles_ptr_len(self.B, self.F), dtype=torch.int32, device=dev)
+        self.key = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)
+        self.val = None if csr.values is None else torch.empty(max(self.nnz, 1), dtype=torch.float32, device=dev)
+        self.lib = torch.empty(self.B, dtype=torch.float32, device=dev) if want_lib else None
+        self.nnan = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(L.scp_tiles_ws_len(self.B, self.F), dtype=torch.int32, device=dev)
+        _lib.check(L.scp_tiles_build(_lib.ptr(csr.indptr), _lib.ptr(csr.indices), _lib.ptr(csr.values),
+                                     _lib.ptr(rows_dev), self.B, self.F, _lib.ptr(self.ptr), _lib.ptr(self.key),
+                                     _lib.ptr(self.val), _lib.ptr(self.lib), _lib.ptr(self.nnan), _lib.ptr(ws),
+                                     _lib.stream()), "scp_tiles_build")
+        self.csr = csr
+
+    @property
+    def shape(self):
+        return (self.B, self.F)
+
+    def to_dense(self):
+        """Dense [B, F] fp32 tensor on the device (tests / tiny inference only)."""
+        ptr = self.ptr.cpu().numpy().astype(np.int64)
+        key = self.key.cpu().numpy()[: self.nnz]
+        val = np.ones(self.nnz, np.float32) if self.val is None else self.val.cpu().numpy()[: self.nnz]
+        ncb = (self.B + 63) // 64
+        out = np.zeros((self.B, self.F), np.float32)
+        starts = ptr[: ncb * self.F + 1]
+        cb_of = np.searchsorted(starts[:: self.F][1:], np.arange(self.nnz), side="right")
+        out[cb_of * 64 + (key & 63), key >> 6] = val
+        return torch.from_numpy(out).to(self.ptr.device)

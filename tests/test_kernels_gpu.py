@@ -1,0 +1,362 @@
+"""GPU parity tests of every C-ABI kernel against the CPU oracle / golden fixtures.
+
+All calls go through libscpair_hip.so (ctypes, C ABI).  Tolerances:
+  precision 'fp32' (ns=3): values rel 2e-5 + abs 1e-6 unless stated (fp32 summation-order noise)
+  precision 'bf16' (ns=1): rel 2e-2 of the output scale (bf16 operand rounding, fp32 accumulate)
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import scpair_amd.ops as ops
+    import scpair_amd.sparse as sparse
+    from oracle import ref_cpu as O
+    return type("S", (), dict(ops=ops, sparse=sparse, O=O, dev=torch.device("cuda:0")))
+
+
+def relerr(a, b):
+    a = a.detach().double().cpu(); b = torch.as_tensor(b).double().cpu().reshape(a.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def close(a, b, rtol=2e-5, atol=1e-6, what=""):
+    a = a.detach().double().cpu(); b = torch.as_tensor(b).double().cpu().reshape(a.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"{what}: max err {float(err.max())} (scale {float(b.abs().max())}), worst tol ratio {float((err / tol).max())}"
+
+
+def rand_csr(rng, n, f, density, binary=False, nan_frac=0.0):
+    import scipy.sparse as sp
+    m = sp.random(n, f, density=density, format="csr", random_state=np.random.RandomState(int(rng.integers(1 << 30))),
+                  data_rvs=lambda k: rng.integers(1, 30, size=k).astype(np.float32))
+    m.sort_indices()
+    if binary:
+        m.data[:] = 1.0
+    if nan_frac > 0:
+        m.data[rng.uniform(size=m.nnz) < nan_frac] = np.nan
+    return m
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,f,b,density", [(300, 97, 130, 0.2), (1000, 2051, 257, 0.03), (64, 5, 64, 0.5), (10, 40, 3, 0.0)])
+def test_tiles_build(S, n, f, b, density):
+    rng = np.random.default_rng(0)
+    m = rand_csr(rng, n, f, density, nan_frac=0.05 if density > 0.1 else 0)
+    csr = S.sparse.DeviceCSR.from_scipy(m, S.dev)
+    rows = rng.permutation(n)[:b]
+    t = S.sparse.BatchTiles(csr, rows)
+    dense = np.asarray(m[rows].todense(), dtype=np.float32)
+    got = t.to_dense().cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(dense))
+    np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(dense))
+    np.testing.assert_allclose(t.lib.cpu().numpy(), np.nansum(dense, 1), rtol=1e-6)
+    assert int(t.nnan.item()) == int(np.isnan(dense).sum())
+    ptr = t.ptr.cpu().numpy()
+    assert ptr[0] == 0 and ptr[((b + 63) // 64) * f] == t.nnz
+    assert np.all(np.diff(ptr[: ((b + 63) // 64) * f + 1]) >= 0)
+
+
+def test_tiles_implicit_ones(S):
+    rng = np.random.default_rng(1)
+    m = rand_csr(rng, 200, 333, 0.05, binary=True)
+    csr = S.sparse.DeviceCSR.from_scipy(m, S.dev, binary=True)
+    assert csr.values is None
+    rows = np.arange(200)[::-1].copy()
+    t = S.sparse.BatchTiles(csr, rows)
+    np.testing.assert_array_equal(t.to_dense().cpu().numpy(), np.asarray(m[rows].todense(), dtype=np.float32))
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 40, 900), (130, 900, 2000), (37, 5, 19), (64, 1, 40), (257, 130, 64), (8, 8, 8)])
+@pytest.mark.parametrize("ns", [3, 1])
+def test_gemm_nt(S, M, N, K, ns):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g); Bm = torch.randn(N, K, generator=g); bias = torch.randn(N, generator=g)
+    Ad, Bd = A.to(S.dev), Bm.to(S.dev)
+    C = torch.empty(M, N, device=S.dev)
+    S.ops.gemm_nt(M, N, K, Ad, K, 1, Bd, K, 1, C, N, bias=bias.to(S.dev), ns=ns)
+    if ns == 3:
+        ref = A.double() @ Bm.double().t() + bias.double()
+        close(C, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()), what="gemm ns3")
+    else:
+        ref = A.bfloat16().double() @ Bm.bfloat16().double().t() + bias.double()
+        close(C, ref, rtol=1e-5, atol=2e-5 * float(ref.abs().max()), what="gemm ns1 vs bf16-rounded inputs")
+    # split-K slabs + reduce
+    nsplit = S.ops._lib.lib().scp_gemm_split_count(K, 4)
+    slabs = torch.empty(nsplit, M, N, device=S.dev)
+    S.ops.gemm_nt(M, N, K, Ad, K, 1, Bd, K, 1, slabs, N, nsplit=nsplit, ns=3)
+    ref = A.double() @ Bm.double().t()
+    close(slabs.sum(0), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()), what="gemm split-K")
+
+
+@pytest.mark.parametrize("M,K,N", [(130, 77, 40), (1024, 900, 40), (50, 40, 1)])
+def test_linear_autograd(S, M, K, N):
+    S.ops.set_precision("fp32")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.1; b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xr, Wr, br = [t.clone().double().requires_grad_(True) for t in (x, W, b)]
+    yr = xr @ Wr.t() + br
+    gx, gW, gb = torch.autograd.grad((yr * dy.double()).sum(), [xr, Wr, br])
+    xd, Wd, bd = [t.to(S.dev).requires_grad_(True) for t in (x, W, b)]
+    y = S.ops.linear(xd, Wd, bd)
+    (y * dy.to(S.dev)).sum().backward()
+    s = lambda t: 1e-5 * float(t.abs().max())
+    close(y, yr, rtol=1e-5, atol=s(yr)); close(xd.grad, gx, rtol=1e-5, atol=s(gx))
+    close(Wd.grad, gW, rtol=1e-5, atol=s(gW)); close(bd.grad, gb, rtol=1e-5, atol=s(gb))
+
+
+@pytest.mark.parametrize("B,F,H,C,ln,p_sparse", [(130, 333, 16, 0, True, True), (257, 2051, 900, 3, True, True),
+                                                 (64, 64, 8, 0, False, True), (100, 50, 40, 4, True, False)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fcnn_layer(S, B, F, H, C, ln, p_sparse, prec):
+    """Linear -> [LayerNorm] -> LeakyReLU on sparse (tile list) or dense input, fwd + all grads, vs torch fp64."""
+    S.ops.set_precision(prec)
+    rng = np.random.default_rng(B + F)
+    m = rand_csr(rng, B + 20, F, 0.08)
+    rows = rng.permutation(B + 20)[:B]
+    xdense = torch.tensor(np.asarray(m[rows].todense(), dtype=np.float32))
+    g = torch.Generator().manual_seed(3)
+    W = torch.randn(H, F + C, generator=g) * (1.0 / np.sqrt(F)); b = torch.randn(H, generator=g) * 0.1
+    gamma = 1 + 0.1 * torch.randn(H, generator=g); beta = 0.1 * torch.randn(H, generator=g)
+    cov = torch.randn(B, C, generator=g) if C else None
+    dout = torch.randn(B, H, generator=g)
+    # reference in fp64 (bf16 mode: operands rounded like the kernel does)
+    rnd = (lambda t: t.bfloat16().double()) if prec == "bf16" else (lambda t: t.double())
+    Wr = W.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True); ber = beta.double().requires_grad_(True)
+    xin = xdense if cov is None else torch.cat([xdense, cov], 1)
+    Wq = Wr if prec == "fp32" else (Wr + (rnd(W) - W.double()).detach())
+    y = rnd(xin) @ Wq.t() + br
+    if ln:
+        y = torch.nn.functional.layer_norm(y, (H,), gr, ber)
+    out_r = torch.nn.functional.leaky_relu(y, 0.01)
+    params = [Wr, br] + ([gr, ber] if ln else [])
+    grads_r = torch.autograd.grad((out_r * dout.double()).sum(), params)
+    # device
+    Wd, bd = W.to(S.dev).requires_grad_(True), b.to(S.dev).requires_grad_(True)
+    gd = gamma.to(S.dev).requires_grad_(True) if ln else None
+    bed = beta.to(S.dev).requires_grad_(True) if ln else None
+    if p_sparse:
+        x_in = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(m, S.dev), rows)
+    else:
+        x_in = xdense.to(S.dev)
+    out = S.ops.fcnn_layer(x_in, None if cov is None else cov.to(S.dev), Wd, bd, gd, bed, 0.01)
+    (out * dout.to(S.dev)).sum().backward()
+    tol = dict(rtol=2e-4, atol=2e-5) if prec == "fp32" else dict(rtol=2e-2, atol=2e-2)
+    sc = lambda t: tol["atol"] * max(1.0, float(t.abs().max()))
+    close(out, out_r, rtol=tol["rtol"], atol=sc(out_r), what="fcnn out")
+    got = [Wd.grad, bd.grad] + ([gd.grad, bed.grad] if ln else [])
+    for name, a, r_ in zip(["dW", "db", "dgamma", "dbeta"], got, grads_r):
+        close(a, r_, rtol=tol["rtol"], atol=sc(r_), what=f"fcnn {name}")
+
+
+def test_fcnn_layer_dropout_mask_consistency(S):
+    """Dropout: kept fraction ~ 1-p, scale 1/(1-p), and backward uses the same mask as forward."""
+    S.ops.set_precision("fp32")
+    B, F, H, p = 256, 64, 128, 0.3
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, F, generator=g).to(S.dev).requires_grad_(True)
+    W = (torch.randn(H, F, generator=g) * 0.2).to(S.dev).requires_grad_(True)
+    b = torch.zeros(H, device=S.dev, requires_grad=True)
+    out0 = S.ops.fcnn_layer(x, None, W, b, None, None, 1.0, 0.0, 7)         # slope 1 => identity activation
+    out = S.ops.fcnn_layer(x, None, W, b, None, None, 1.0, p, 7)
+    kept = (out != 0)
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    close(out[kept], (out0 / (1 - p))[kept], rtol=1e-5, atol=1e-6)
+    out.sum().backward()
+    # d out / d b = column count of kept entries / (1-p)
+    close(b.grad, kept.float().sum(0) / (1 - p), rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------
+def _ber_case(S, d, tag, prec):
+    c = U.cfg(d, f"{tag}/cfg")
+    sd = U.sub(d, f"{tag}/sd")
+    h = torch.tensor(d[f"{tag}/h"]); cov = U.opt(d, f"{tag}/cov")
+    y = torch.tensor(d[f"{tag}/y"])
+    lib, latlib = U.opt(d, f"{tag}/lib"), U.opt(d, f"{tag}/latlib")
+    lrow = lib if c["sf"] else latlib
+    hin = h if cov is None else torch.cat([h, cov], 1)
+    hd = hin.to(S.dev).requires_grad_(True)
+    Wd = sd["output_layer.weight"].to(S.dev).requires_grad_(True)
+    bd = sd["output_layer.bias"].to(S.dev).requires_grad_(True)
+    fsd = sd["feature_scalar"].to(S.dev).requires_grad_(True) if c["ff"] else None
+    ld = lrow.to(S.dev).requires_grad_(True) if lrow is not None else None
+    tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_dense(y, S.dev), np.arange(y.shape[0]))
+    S.ops.set_precision(prec)
+    loss = S.ops.ber_decoder_loss(hd, Wd, bd, fsd, ld, tiles)
+    loss.backward()
+    return c, loss, hd, Wd, bd, fsd, ld
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ber_decoder_golden(S, prec):
+    d = U.load("mod_ber")
+    tol = dict(rtol=1e-4, atol=1e-7) if prec == "fp32" else dict(rtol=3e-2, atol=3e-4)
+    for tag in json.loads(str(d["cases"])):
+        c, loss, hd, Wd, bd, fsd, ld = _ber_case(S, d, tag, prec)
+        close(loss, d[f"{tag}/loss"], rtol=1e-5 if prec == "fp32" else 5e-3, atol=0, what=f"{tag} loss")
+        n_lat = d[f"{tag}/h"].shape[1]
+        sc = lambda a: tol["atol"] + tol["rtol"] * float(np.abs(a).max())
+        close(hd.grad[:, :n_lat], d[f"{tag}/dh"], rtol=tol["rtol"], atol=sc(d[f"{tag}/dh"]), what=f"{tag} dh")
+        close(Wd.grad, d[f"{tag}/grad/output_layer.weight"], rtol=tol["rtol"], atol=sc(d[f"{tag}/grad/output_layer.weight"]), what=f"{tag} dW")
+        close(bd.grad, d[f"{tag}/grad/output_layer.bias"], rtol=tol["rtol"], atol=sc(d[f"{tag}/grad/output_layer.bias"]), what=f"{tag} db")
+        if c["ff"]:
+            close(fsd.grad, d[f"{tag}/grad/feature_scalar"], rtol=tol["rtol"], atol=sc(d[f"{tag}/grad/feature_scalar"]), what=f"{tag} dfs")
+        if f"{tag}/dlatlib" in d.files:
+            close(ld.grad, d[f"{tag}/dlatlib"], rtol=tol["rtol"], atol=sc(d[f"{tag}/dlatlib"]), what=f"{tag} dlatlib")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_nb_decoder_golden(S, prec):
+    d = U.load("mod_raw")
+    tol = dict(rtol=2e-4, atol=1e-7) if prec == "fp32" else dict(rtol=3e-2, atol=3e-4)
+    n_done = 0
+    for tag in json.loads(str(d["cases"])):
+        c = U.cfg(d, f"{tag}/cfg")
+        if c["lik"] != "nb":
+            continue
+        sd = U.sub(d, f"{tag}/sd")
+        h = torch.tensor(d[f"{tag}/h"]); cov = U.opt(d, f"{tag}/cov"); y = torch.tensor(d[f"{tag}/y"])
+        hin = h if cov is None else torch.cat([h, cov], 1)
+        hd = hin.to(S.dev).requires_grad_(True)
+        Wd = sd["output_mean.0.weight"].to(S.dev).requires_grad_(True)
+        bd = sd["output_mean.0.bias"].to(S.dev).requires_grad_(True)
+        fsd = sd["feature_scalar"].to(S.dev).requires_grad_(True) if c["ff"] else None
+        thd = sd["output_inverse_dispersion"].to(S.dev).requires_grad_(True) if c["disp"] == "feature" else None
+        if c["sf"]:
+            L = torch.tensor(d[f"{tag}/lib"]).to(S.dev); lat = None
+        else:
+            lat = torch.tensor(d[f"{tag}/latlib"]).to(S.dev).requires_grad_(True)
+            L = torch.exp(torch.nn.functional.leaky_relu(lat.detach(), 0.01))
+        tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_dense(y, S.dev), np.arange(y.shape[0]))
+        S.ops.set_precision(prec)
+        loss = S.ops.nb_decoder_loss(hd, Wd, bd, fsd, thd, L, lat, tiles)
+        loss.backward()
+        close(loss, d[f"{tag}/loss"], rtol=2e-5 if prec == "fp32" else 5e-3, atol=0, what=f"{tag} loss")
+        sc = lambda a: tol["atol"] + tol["rtol"] * float(np.abs(a).max())
+        n_lat = h.shape[1]
+        close(hd.grad[:, :n_lat], d[f"{tag}/dh"], rtol=tol["rtol"], atol=sc(d[f"{tag}/dh"]), what=f"{tag} dh")
+        close(Wd.grad, d[f"{tag}/grad/output_mean.0.weight"], rtol=tol["rtol"], atol=sc(d[f"{tag}/grad/output_mean.0.weight"]), what=f"{tag} dW")
+        close(bd.grad, d[f"{tag}/grad/output_mean.0.bias"], rtol=tol["rtol"], atol=sc(d[f"{tag}/grad/output_mean.0.bias"]), what=f"{tag} db")
+        if c["ff"]:
+            close(fsd.grad, d[f"{tag}/grad/feature_scalar"], rtol=tol["rtol"], atol=sc(d[f"{tag}/grad/feature_scalar"]), what=f"{tag} dfs")
+        if c["disp"] == "feature":
+            close(thd.grad, d[f"{tag}/grad/output_inverse_dispersion"], rtol=tol["rtol"], atol=sc(d[f"{tag}/grad/output_inverse_dispersion"]), what=f"{tag} dtheta")
+        if not c["sf"]:
+            close(lat.grad, d[f"{tag}/dlatlib"], rtol=tol["rtol"], atol=sc(d[f"{tag}/dlatlib"]), what=f"{tag} dlat")
+        n_done += 1
+    assert n_done >= 6
+
+
+@pytest.mark.parametrize("B,F,K", [(130, 2051, 40), (257, 333, 11)])
+def test_decoders_larger_vs_oracle(S, B, F, K):
+    """Ragged sizes (cells not a multiple of 64, features not a multiple of 256) against the CPU oracle."""
+    O = S.O
+    S.ops.set_precision("fp32")
+    rng = np.random.default_rng(F)
+    g = torch.Generator().manual_seed(F)
+    h = torch.randn(B, K, generator=g) * 0.5
+    W = torch.randn(F, K, generator=g) * 0.3; b = torch.randn(F, generator=g) * 0.5 - 1.0
+    lat = torch.randn(B, 1, generator=g)
+    # Bernoulli with latent_lib
+    yb = rand_csr(rng, B, F, 0.05, binary=True)
+    ybd = torch.tensor(np.asarray(yb.todense(), dtype=np.float32))
+    hr, Wr, br, lr = [t.clone().requires_grad_(True) for t in (h, W, b, lat)]
+    res = O.output_ber({"output_layer.weight": Wr, "output_layer.bias": br}, hr, None, None, lr, sample_factor=False)
+    lo = O.bce_masked(ybd, res[0]); lo.backward()
+    hd, Wd, bd, ld = [t.clone().to(S.dev).requires_grad_(True) for t in (h, W, b, lat)]
+    tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(yb, S.dev, binary=True), np.arange(B))
+    l = S.ops.ber_decoder_loss(hd, Wd, bd, None, ld, tiles); l.backward()
+    close(l, lo, rtol=2e-5, atol=0, what="ber loss")
+    for nm, a, r_ in [("dh", hd.grad, hr.grad), ("dW", Wd.grad, Wr.grad), ("db", bd.grad, br.grad), ("dl", ld.grad, lr.grad)]:
+        close(a, r_, rtol=2e-4, atol=2e-4 * float(r_.abs().max()), what=f"ber {nm}")
+    # NB with library size
+    yn = rand_csr(rng, B, F, 0.1)
+    ynd = torch.tensor(np.asarray(yn.todense(), dtype=np.float32))
+    lib = ynd.sum(1, keepdim=True)
+    hr, Wr, br = [t.clone().requires_grad_(True) for t in (h, W, b + 1.0)]
+    scale, theta, rate, _ = O.output_raw({"output_mean.0.weight": Wr, "output_mean.0.bias": br}, hr, None, lib, None, True)
+    lo = O.raw_loss(ynd, rate, theta, None, "nb"); lo.backward()
+    hd, Wd, bd = [t.clone().to(S.dev).requires_grad_(True) for t in (h, W, b + 1.0)]
+    tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(yn, S.dev), np.arange(B))
+    close(tiles.lib, lib, rtol=1e-6, atol=0)
+    l = S.ops.nb_decoder_loss(hd, Wd, bd, None, None, tiles.lib, None, tiles); l.backward()
+    close(l, lo, rtol=5e-5, atol=0, what="nb loss")
+    for nm, a, r_ in [("dh", hd.grad, hr.grad), ("dW", Wd.grad, Wr.grad), ("db", bd.grad, br.grad)]:
+        close(a, r_, rtol=5e-4, atol=5e-4 * float(r_.abs().max()), what=f"nb {nm}")
+
+
+def test_ber_eval_mode_matches_train_loss(S):
+    S.ops.set_precision("fp32")
+    d = U.load("mod_ber")
+    tag = json.loads(str(d["cases"]))[0]
+    sd = U.sub(d, f"{tag}/sd")
+    y = torch.tensor(d[f"{tag}/y"])
+    tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_dense(y, S.dev), np.arange(y.shape[0]))
+    with torch.no_grad():
+        l = S.ops.ber_decoder_loss(torch.tensor(d[f"{tag}/h"]).to(S.dev), sd["output_layer.weight"].to(S.dev),
+                                   sd["output_layer.bias"].to(S.dev), None, None, tiles)
+    close(l, d[f"{tag}/loss"], rtol=1e-5, atol=0)
+
+
+# ------------------------------------------------------------------------------------------
+def test_mse_and_reparam(S):
+    b = U.load("kat_bce_mse")
+    x = torch.tensor(b["mse_x"]).to(S.dev); mu = torch.tensor(b["mse_mu"]).to(S.dev).requires_grad_(True)
+    l = S.ops.mse_masked(x, mu); l.backward()
+    close(l, b["mse_loss"], rtol=1e-6); close(mu.grad, b["mse_dmu"], rtol=1e-5, atol=1e-8)
+    g = torch.Generator().manual_seed(0)
+    m_ = torch.randn(33, 7, generator=g); s_ = torch.randn(33, 7, generator=g) * 3; e_ = torch.randn(33, 7, generator=g)
+    s_[0, 0] = 25.0; s_[0, 1] = -30.0
+    w = torch.randn(33, 7, generator=g)
+    mr, sr = m_.clone().double().requires_grad_(True), s_.clone().double().requires_grad_(True)
+    sig = torch.nn.functional.softplus(sr) + 1e-7
+    z = mr + e_.double() * sig
+    kl = S.O.kl_normal(mr, sig)
+    (0.7 * kl + (z * w.double()).sum()).backward()
+    md, sd_ = m_.to(S.dev).requires_grad_(True), s_.to(S.dev).requires_grad_(True)
+    sigma, zd, kld = S.ops.reparam_kl(md, sd_, e_.to(S.dev))
+    (0.7 * kld + (zd * w.to(S.dev)).sum()).backward()
+    close(sigma, sig, rtol=1e-5, atol=1e-9); close(zd, z, rtol=1e-5, atol=1e-6); close(kld, kl, rtol=1e-5)
+    close(md.grad, mr.grad, rtol=1e-5, atol=1e-6); close(sd_.grad, sr.grad, rtol=2e-5, atol=1e-6)
+
+
+def test_adamw_golden(S):
+    d = U.load("adamw_traj")
+    pa = torch.nn.Parameter(torch.tensor(d["init_0"]).to(S.dev)); pb = torch.nn.Parameter(torch.tensor(d["init_1"]).to(S.dev))
+    opt = S.ops.FusedAdamW([{"params": [pa], "weight_decay": 1e-2, "lr": 1e-3}, {"params": [pb], "weight_decay": 0, "lr": 1e-3}])
+    for s in range(5):
+        pa.grad = torch.tensor(d[f"g{s}_0"]).to(S.dev); pb.grad = torch.tensor(d[f"g{s}_1"]).to(S.dev)
+        opt.step()
+        close(pa, d[f"p{s}_0"], rtol=1e-6, atol=1e-7); close(pb, d[f"p{s}_1"], rtol=1e-6, atol=1e-7)
+    close(opt.state[pa]["exp_avg"], d["m_final_0"], rtol=1e-5, atol=1e-8)
+    close(opt.state[pa]["exp_avg_sq"], d["v_final_0"], rtol=1e-5, atol=1e-10)
+    # large, oddly sized tensor vs torch.optim.AdamW on the CPU
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(100003, generator=g); gr = torch.randn(100003, generator=g)
+    pc = torch.nn.Parameter(p0.clone()); oc = torch.optim.AdamW([pc], lr=1e-3, weight_decay=1e-9)
+    pd = torch.nn.Parameter(p0.clone().to(S.dev)); od = S.ops.FusedAdamW([pd], lr=1e-3, weight_decay=1e-9)
+    for _ in range(3):
+        pc.grad = gr.clone(); oc.step()
+        pd.grad = gr.clone().to(S.dev); od.step()
+    close(pd, pc.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_error_reporting(S):
+    L = S.ops._lib.lib()
+    rc = L.scp_gemm_nt(0, 1, 1, None, 1, 1, None, 1, 1, None, 1, None, 0, 1, 3, None)
+    assert rc == -1 and b"positive" in L.scp_last_error()
+    with pytest.raises(RuntimeError):
+        S.ops.linear(torch.randn(4, 4), torch.randn(4, 4), None)        # CPU tensors are refused, no fallback
