@@ -92,6 +92,18 @@ int scp_mse_masked_fwd(const float* x, long ldx, const float* mu, long ldm, int 
 int scp_mse_masked_bwd(const float* x, long ldx, const float* mu, long ldm, int rows, int cols,
                        const float* loss_cnt, const float* gout, float* dmu, long ldd, void* stream);
 
+/* ---- stand-alone likelihoods on dense tensors (the reference's own call form) ----
+ *      binarized_loss(x, p) (loss.py:36-41); log_nb_positive / log_zinb_positive element-wise
+ *      (scVI_distribution.py:29-105; pi == NULL selects NB; theta_vec != 0: theta is a [cols] vector) ---- */
+int scp_bce_masked_fwd(const float* x, const float* p, long n, float* loss_cnt /* [2] */, double* ws /* >= 520 */,
+                       void* stream);
+int scp_bce_masked_bwd(const float* x, const float* p, long n, const float* loss_cnt, const float* gout, float* dp,
+                       void* stream);
+int scp_nbll_fwd(const float* x, const float* mu, const float* theta, int theta_vec, int cols, const float* pi,
+                 long n, float* out, void* stream);
+int scp_nbll_bwd(const float* x, const float* mu, const float* theta, int theta_vec, int cols, const float* pi,
+                 const float* g, long n, float* dmu, float* dtheta, float* dpi, void* stream);
+
 /* ---- VAE bottleneck: softplus + 1e-7, reparameterise (pairedVAE.py:51-58), KL mean (utils.py:186) ---- */
 int scp_reparam_kl_fwd(const float* mu, const float* sraw, const float* eps, long n, float* sigma, float* z,
                        float* kl /* [1] */, double* ws /* >= 520 */, void* stream);

@@ -51,6 +51,10 @@ _SIGS = {
     "scp_nb_dec_ll": (I, [I, I, I, I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, L, P, P, P, P, I, P]),
     "scp_mse_masked_fwd": (I, [P, L, P, L, I, I, P, P, P]),
     "scp_mse_masked_bwd": (I, [P, L, P, L, I, I, P, P, P, L, P]),
+    "scp_bce_masked_fwd": (I, [P, P, L, P, P, P]),
+    "scp_bce_masked_bwd": (I, [P, P, L, P, P, P, P]),
+    "scp_nbll_fwd": (I, [P, P, P, I, I, P, L, P, P]),
+    "scp_nbll_bwd": (I, [P, P, P, I, I, P, P, L, P, P, P, P]),
     "scp_reparam_kl_fwd": (I, [P, P, P, L, P, P, P, P, P]),
     "scp_reparam_kl_bwd": (I, [P, P, P, P, P, P, P, L, P, P, P]),
     "scp_ber_prob": (I, [P, L, I, I, P, I, P, P, L, P]),

@@ -235,3 +235,143 @@ extern "C" int scp_relu_softmax_rows(const float* z, long ldz, int rows, int col
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
+
+// ---- masked BCE on probabilities (stand-alone form of loss.py:36-41) -----------------------------------
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ p, long n,
+                                                      double* __restrict__ part) {
+  __shared__ double red[8];
+  double s = 0.0, cnt = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float xv = x[i];
+    if (xv == xv) {
+      float q = p[i];
+      s -= (double)(xv * fmaxf(logf(q), -100.f) + (1.f - xv) * fmaxf(logf(1.f - q), -100.f));
+      cnt += 1.0;
+    }
+  }
+  s = block_sum_d(s, red);
+  cnt = block_sum_d(cnt, red);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = s;
+    part[2 * blockIdx.x + 1] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ p, long n,
+                                                      const float* __restrict__ loss_cnt, const float* __restrict__ gout,
+                                                      float* __restrict__ dp) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float xv = x[i], q = p[i];
+  float sc = (gout ? gout[0] : 1.f) / loss_cnt[1];
+  dp[i] = (xv == xv) ? sc * (q - xv) / fmaxf(q * (1.f - q), 1e-12f) : 0.f;
+}
+
+extern "C" int scp_bce_masked_fwd(const float* x, const float* p, long n, float* loss_cnt, double* ws, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SCP_CHECK(x && p && loss_cnt && ws && n > 0, SCP_ERR_ARG, "scp_bce_masked_fwd: bad argument");
+  int grid = (int)((n + 255) / 256);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, p, n, ws);
+  SCP_LAUNCH_CHECK();
+  int rc = scp_reduce_partials(ws, grid, 2, ws + 512, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(1), 0, stream, ws + 512, loss_cnt);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_bce_masked_bwd(const float* x, const float* p, long n, const float* loss_cnt, const float* gout,
+                                  float* dp, void* stream_) {
+  SCP_CHECK(x && p && loss_cnt && dp && n > 0, SCP_ERR_ARG, "scp_bce_masked_bwd: bad argument");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, p, n,
+                     loss_cnt, gout, dp);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+// ---- element-wise NB / ZINB log-likelihood (scVI_distribution.py:29-105), stand-alone form ---------------
+// theta may be a per-feature vector (theta_cols = number of columns, theta index = i % cols) or full size.
+__global__ __launch_bounds__(256) void nbll_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                       const float* __restrict__ theta, int theta_vec, int cols,
+                                                       const float* __restrict__ pi, long n, float* __restrict__ out) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float eps = 1e-8f;
+  float xv = x[i], m = mu[i], th = theta[theta_vec ? (i % cols) : i];
+  float s = th + m + eps;
+  float lt = logf(th + eps), ls = logf(s);
+  if (!pi) {
+    // reference evaluates every term for every element (x = 0 makes the lgamma terms cancel)
+    out[i] = th * (lt - ls) + xv * (logf(m + eps) - ls) + lgammaf(xv + th) - lgammaf(th) - lgammaf(xv + 1.f);
+  } else {
+    float pv = pi[i];
+    float sp = softplus_t(-pv);
+    float t = -pv + th * (lt - ls);
+    float c0 = softplus_t(t) - sp;
+    float c1 = -sp + t + xv * (logf(m + eps) - ls) + lgammaf(xv + th) - lgammaf(th) - lgammaf(xv + 1.f);
+    // both branches are computed and 0/1 weighted, as the reference does (0 * inf = NaN is reproduced)
+    out[i] = (xv < eps ? 1.f : 0.f) * c0 + (xv > eps ? 1.f : 0.f) * c1;
+  }
+}
+
+__global__ __launch_bounds__(256) void nbll_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                       const float* __restrict__ theta, int theta_vec, int cols,
+                                                       const float* __restrict__ pi, const float* __restrict__ g, long n,
+                                                       float* __restrict__ dmu, float* __restrict__ dtheta,
+                                                       float* __restrict__ dpi) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float eps = 1e-8f;
+  float xv = x[i], m = mu[i], th = theta[theta_vec ? (i % cols) : i], gv = g[i];
+  float s = th + m + eps;
+  float lt = logf(th + eps), ls = logf(s);
+  float dt_dmu = -th / s;
+  float dt_dth = lt - ls + th / (th + eps) - th / s;
+  float dm, dth, dp = 0.f;
+  bool nz = xv > eps, zero = xv < eps;
+  float dig = nz ? digammaf_pos(xv + th) - digammaf_pos(th) : 0.f;
+  if (!pi) {
+    dm = dt_dmu + xv * (1.f / (m + eps) - 1.f / s);
+    dth = dt_dth - xv / s + dig;
+  } else {
+    float pv = pi[i];
+    float t = -pv + th * (lt - ls);
+    float sig_t = t > 20.f ? 1.f : sigmoidf_(t);
+    float sig_npi = (-pv) > 20.f ? 1.f : sigmoidf_(-pv);
+    if (zero) {
+      dm = sig_t * dt_dmu;
+      dth = sig_t * dt_dth;
+      dp = -sig_t + sig_npi;
+    } else if (nz) {
+      dm = dt_dmu + xv * (1.f / (m + eps) - 1.f / s);
+      dth = dt_dth - xv / s + dig;
+      dp = sig_npi - 1.f;
+    } else {
+      dm = dth = dp = 0.f;
+    }
+  }
+  dmu[i] = gv * dm;
+  dtheta[i] = gv * dth;
+  if (dpi) dpi[i] = gv * dp;
+}
+
+extern "C" int scp_nbll_fwd(const float* x, const float* mu, const float* theta, int theta_vec, int cols,
+                            const float* pi, long n, float* out, void* stream_) {
+  SCP_CHECK(x && mu && theta && out && n > 0 && cols > 0, SCP_ERR_ARG, "scp_nbll_fwd: bad argument");
+  hipLaunchKernelGGL(nbll_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, mu, theta,
+                     theta_vec, cols, pi, n, out);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_nbll_bwd(const float* x, const float* mu, const float* theta, int theta_vec, int cols,
+                            const float* pi, const float* g, long n, float* dmu, float* dtheta, float* dpi,
+                            void* stream_) {
+  SCP_CHECK(x && mu && theta && g && dmu && dtheta && n > 0 && cols > 0, SCP_ERR_ARG, "scp_nbll_bwd: bad argument");
+  SCP_CHECK((pi == nullptr) == (dpi == nullptr), SCP_ERR_ARG, "scp_nbll_bwd: pi and dpi go together");
+  hipLaunchKernelGGL(nbll_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, mu, theta,
+                     theta_vec, cols, pi, g, n, dmu, dtheta, dpi);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}

@@ -1,0 +1,847 @@
+"""scPair modules and trainer with the reference's names, constructor arguments, parameter names and return
+conventions (model.py:60-1036), running on the MI355X HIP kernels.
+
+What changes underneath:
+  * count matrices stay in HBM as CSR (sparse.DeviceCSR); a minibatch is a row-id vector re-bucketed on the GPU
+    into a tile list (sparse.BatchTiles) -- no dense [cells x features] tensor is ever built for training;
+  * the first encoder layer densifies those tiles inside LDS and runs on bf16 MFMA; LayerNorm/activation/dropout
+    are one fused epilogue; decoders are fused with their likelihood and their backward;
+  * AdamW is one fused multi-tensor launch.
+"""
+from __future__ import annotations
+
+import copy
+import gc
+import os
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import ops
+from .loss import binarized_loss, raw_loss, scaled_loss
+from .sparse import BatchTiles, DeviceCSR
+from .utils import (FCNN, HipLinear, add_weight_decay, eval_net, evaluating_mode, init_weights, set_seed,
+                    train_net, training_mode)
+
+
+def clear_gpu_memory():
+    """model.py:42-46 (kept for API compatibility; the HIP path allocates per step through torch's caching allocator)."""
+    gc.collect()
+
+
+def move_to_device_safe(tensor, device):
+    """model.py:49-55."""
+    if tensor is None:
+        return None
+    if isinstance(tensor, (BatchTiles, DeviceCSR)):
+        return tensor
+    if tensor.device == device:
+        return tensor
+    return tensor.to(device, non_blocking=True)
+
+
+class LazyGPUDataset(torch.utils.data.Dataset):
+    """model.py:26-38 (API compatibility only; training uses device-resident CSR instead)."""
+
+    def __init__(self, *tensors, device="cuda"):
+        self.tensors = tensors
+        self.device = device
+        self.length = len(tensors[0]) if tensors else 0
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        return tuple(tensor[idx] for tensor in self.tensors)
+
+
+def _cat_cov(h, cov):
+    return h if cov is None else torch.cat([h, cov], dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class Input_Module(nn.Module):
+    """Encoder (model.py:60-143): latent_rep = [extra_linear_rep](hidden_rep(cat[x, cov])),
+    latent_lib = Linear(hidden_lib_FCNN(cat[x, cov])) if infer_library_size else None."""
+
+    def __init__(self, input_dim: int, input_batch_num: int, hidden_layer, layernorm=True, activation=nn.ReLU(),
+                 batchnorm=False, dropout_rate=0, add_linear_layer=False, infer_library_size=True,
+                 clip_threshold=None):
+        super().__init__()
+        self.infer_library_size = infer_library_size
+        self.add_linear_layer = add_linear_layer
+        self.clip_threshold = clip_threshold
+        self.hidden_rep = FCNN([input_dim + input_batch_num] + hidden_layer, layernorm=layernorm,
+                               activation=activation, batchnorm=batchnorm, dropout_rate=dropout_rate)
+        if self.add_linear_layer is True:
+            self.extra_linear_rep = HipLinear(hidden_layer[-1], hidden_layer[-1], bias=True)
+        if self.infer_library_size == True:  # noqa: E712  (reference spelling)
+            self.hidden_lib = nn.Sequential(FCNN([input_dim + input_batch_num] + hidden_layer, activation=activation,
+                                                 layernorm=layernorm, batchnorm=batchnorm,
+                                                 dropout_rate=dropout_rate),
+                                            HipLinear(hidden_layer[-1], 1, bias=True))
+
+    def forward(self, input, input_batch):
+        latent_rep = self.hidden_rep(input, input_batch)
+        if self.add_linear_layer is True:
+            latent_rep = self.extra_linear_rep(latent_rep)
+        if self.infer_library_size == True:  # noqa: E712
+            latent_lib = self.hidden_lib[1](self.hidden_lib[0](input, input_batch))
+        else:
+            latent_lib = None
+        return latent_rep, latent_lib
+
+
+class Output_Module_Ber(nn.Module):
+    """Bernoulli decoder (model.py:149-190)."""
+
+    def __init__(self, output_dim: int, output_batch_num: int, hidden_layer, infer_library_size=True,
+                 sample_factor=True, feature_factor=True):
+        super().__init__()
+        self.infer_library_size = infer_library_size
+        self.sample_factor = sample_factor
+        self.feature_factor = feature_factor
+        if self.feature_factor == True:  # noqa: E712
+            self.feature_scalar = torch.nn.Parameter(torch.zeros(output_dim))
+        self.output_layer = HipLinear(hidden_layer[-1] + output_batch_num, output_dim, bias=True)
+
+    def _lrow(self, lib, latent_lib):
+        if self.sample_factor == True:  # noqa: E712
+            return lib
+        if latent_lib is not None:
+            return latent_lib
+        return None
+
+    def forward(self, latent_rep, output_batch, lib, latent_lib):
+        """Dense outputs (output_result, output_px, output_sample_factor, output_feature_factor) as in the
+        reference; used by predict().  Training uses fused_loss(), which never materialises them."""
+        latent_rep = _cat_cov(latent_rep, output_batch)
+        self.output_temp = self.output_layer(latent_rep)
+        output_px = torch.sigmoid(self.output_temp)
+        lrow = self._lrow(lib, latent_lib)
+        if lrow is not None:
+            output_sample_factor = torch.sigmoid(lrow)
+            output_result = output_px * output_sample_factor
+        else:
+            output_sample_factor = None
+            output_result = output_px
+        if self.feature_factor == True:  # noqa: E712
+            output_feature_factor = torch.sigmoid(self.feature_scalar)
+            output_result = output_result * output_feature_factor
+        else:
+            output_feature_factor = None
+        return output_result, output_px, output_sample_factor, output_feature_factor
+
+    def fused_loss(self, latent_rep, output_batch, lib, latent_lib, labels, likelihood="ber"):
+        """binarized_loss(labels, forward(...)[0]) in one kernel pass with its backward (no [cells x peaks] tensor)."""
+        h = _cat_cov(latent_rep, output_batch)
+        fs = self.feature_scalar if self.feature_factor == True else None  # noqa: E712
+        return ops.ber_decoder_loss(h, self.output_layer.weight, self.output_layer.bias, fs,
+                                    self._lrow(lib, latent_lib), labels)
+
+
+class Output_Module_Raw(nn.Module):
+    """(ZI)NB decoder (model.py:196-259).  Keeps the reference's quirks: for dispersion='feature-cell' an unused
+    Linear(G, G) `output_inverse_dispersion` is allocated (state_dict compatibility), and `zero_inflated` is
+    independent of the 'nb'/'zinb' likelihood string."""
+
+    def __init__(self, output_dim: int, output_batch_num: int, hidden_layer, infer_library_size=True,
+                 sample_factor=True, feature_factor=False, zero_inflated=True, dispersion="feature-cell", eps=1e-8):
+        super().__init__()
+        self.infer_library_size = infer_library_size
+        self.sample_factor = sample_factor
+        self.feature_factor = feature_factor
+        self.zero_inflated = zero_inflated
+        self.dispersion = dispersion
+        self.epsilon = eps
+        if self.feature_factor == True:  # noqa: E712
+            self.feature_scalar = torch.nn.Parameter(torch.zeros(output_dim))
+        self.output_mean = nn.Sequential(HipLinear(hidden_layer[-1] + output_batch_num, output_dim, bias=True),
+                                         nn.ReLU())
+        self.transformation_function = nn.LeakyReLU()
+        self.scale_function = nn.Softmax(dim=-1)
+        if self.dispersion == "feature":
+            self.output_inverse_dispersion = torch.nn.Parameter(torch.randn(output_dim))
+        elif self.dispersion == "feature-cell":
+            self.output_inverse_dispersion = HipLinear(output_dim, output_dim, bias=True)
+        if self.zero_inflated == True:  # noqa: E712
+            self.output_dropout = HipLinear(output_dim, output_dim, bias=True)
+
+    def forward(self, latent_rep, output_batch, lib, latent_lib):
+        latent_rep = _cat_cov(latent_rep, output_batch)
+        px_mu = self.output_mean(latent_rep)
+        if self.feature_factor == True:  # noqa: E712
+            px_mu_scale = self.scale_function(px_mu * torch.sigmoid(self.feature_scalar))
+        else:
+            px_mu_scale = self.scale_function(px_mu)
+        if self.sample_factor == True:  # noqa: E712
+            px_mu_rate = lib * px_mu_scale
+        elif latent_lib is not None:
+            px_mu_rate = torch.exp(self.transformation_function(latent_lib)) * px_mu_scale
+        else:
+            raise Exception("The library size is missing. Please ensure that either the 'sample_factor' or "
+                            "'infer_library_size' parameter for the raw counts decoder is set to True.")
+        if self.dispersion == "feature":
+            px_theta = torch.exp(self.output_inverse_dispersion)
+        elif self.dispersion == "feature-cell":
+            px_theta = torch.exp(px_mu)
+        if self.zero_inflated == True:  # noqa: E712
+            px_pi = self.output_dropout(px_mu)
+        else:
+            px_pi = None
+        return px_mu_scale, px_theta, px_mu_rate, px_pi
+
+    def fused_loss(self, latent_rep, output_batch, lib, latent_lib, labels, likelihood="nb"):
+        """raw_loss(labels, *forward(...)) for likelihood 'nb' in three fused kernel passes (row softmax statistics,
+        likelihood, gradients).  Returns None for 'zinb' (the G x G zero-inflation layer needs the materialised
+        form: forward() + raw_loss)."""
+        if likelihood != "nb":
+            return None
+        h = _cat_cov(latent_rep, output_batch)
+        fs = self.feature_scalar if self.feature_factor == True else None  # noqa: E712
+        thp = self.output_inverse_dispersion if self.dispersion == "feature" else None
+        if self.sample_factor == True:  # noqa: E712
+            L, lat = lib, None
+        elif latent_lib is not None:
+            lat = latent_lib
+            L = torch.exp(F.leaky_relu(latent_lib.detach(), 0.01))
+        else:
+            raise Exception("The library size is missing. Please ensure that either the 'sample_factor' or "
+                            "'infer_library_size' parameter for the raw counts decoder is set to True.")
+        lin = self.output_mean[0]
+        return ops.nb_decoder_loss(h, lin.weight, lin.bias, fs, thp, L, lat, labels)
+
+
+class Output_Module_Gau(nn.Module):
+    """Gaussian decoder (model.py:268-300)."""
+
+    def __init__(self, output_dim: int, output_batch_num: int, hidden_layer, infer_library_size=True,
+                 feature_factor=False):
+        super().__init__()
+        self.infer_library_size = infer_library_size
+        self.feature_factor = feature_factor
+        if self.feature_factor == True:  # noqa: E712
+            self.feature_scalar = torch.nn.Parameter(torch.zeros(output_dim))
+        self.output_layer = HipLinear(hidden_layer[-1] + output_batch_num + self.infer_library_size, output_dim,
+                                      bias=True)
+
+    def forward(self, latent_rep, output_batch, lib, latent_lib):
+        latent_rep = _cat_cov(latent_rep, output_batch)
+        if latent_lib is not None:
+            latent_rep = torch.cat([latent_rep, latent_lib], dim=1)
+        self.output_temp = self.output_layer(latent_rep)
+        if self.feature_factor == True:  # noqa: E712
+            return self.output_temp * self.feature_scalar
+        return self.output_temp
+
+
+class Module_Module(nn.Module):
+    """Latent translation network (model.py:305-336)."""
+
+    def __init__(self, origin_module_dim: int, target_module_dim: int, translational_hidden_nodes, non_neg=True,
+                 layernorm=False, activation=nn.ReLU(), batchnorm=False, dropout_rate=0):
+        super().__init__()
+        self.nonneg = non_neg
+        self.translational_hidden_nodes = translational_hidden_nodes
+        if self.translational_hidden_nodes is not None:
+            self.translate = nn.Sequential(FCNN([origin_module_dim] + translational_hidden_nodes,
+                                                activation=activation, batchnorm=batchnorm, layernorm=layernorm,
+                                                dropout_rate=dropout_rate),
+                                           HipLinear(translational_hidden_nodes[-1], target_module_dim, bias=True))
+        else:
+            self.translate = HipLinear(origin_module_dim, target_module_dim, bias=True)
+
+    def forward(self, x):
+        translation = self.translate(x)
+        if self.nonneg == True:  # noqa: E712
+            translation = torch.clamp(translation, min=0)
+        return translation
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _Index:
+    def __init__(self, n):
+        self.index = np.arange(n)
+
+
+def _to_csr(v, device, binary=False):
+    """dict-seam value -> DeviceCSR.  Accepts the reference's dense FloatTensor, scipy sparse, or DeviceCSR."""
+    if isinstance(v, DeviceCSR):
+        return v
+    if isinstance(v, torch.Tensor) or isinstance(v, np.ndarray):
+        return DeviceCSR.from_dense(v, device)
+    return DeviceCSR.from_scipy(v, device, binary=binary)
+
+
+def _index_loader(n, batch_size, drop_last=False):
+    """A DataLoader over row ids built exactly like the reference's (model.py:713-717: shuffle=True,
+    num_workers=0), so it draws from the global torch RNG the same way and yields the same batch composition."""
+    ds = torch.utils.data.TensorDataset(torch.arange(n))
+    return torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=0, drop_last=drop_last)
+
+
+class scPair_object():
+    """model.py:341-1036.  Same constructor surface; `device` must be a GPU."""
+
+    def __init__(self,
+                 scobj,
+                 modalities={'Gene Expression': 'zinb', 'Peaks': 'ber'},
+                 cov=['labels'],
+                 SEED=0,
+                 hidden_layer=[900, 40],
+                 dropout_rate=0.1,
+                 batchnorm=False,
+                 layernorm=True,
+                 learning_rate_prediction=1e-3,
+                 batch_size=130,
+                 L2_lambda=1e-9,
+                 max_epochs=1000,
+                 activation=nn.LeakyReLU(),
+                 early_stopping_activation=True,
+                 early_stopping_patience=25,
+                 weight_decay=None,
+                 device=None,
+                 save_model=True,
+                 save_path=None,
+                 input_module=Input_Module,
+                 output_module={'nb': Output_Module_Raw, 'zinb': Output_Module_Raw, 'ber': Output_Module_Ber,
+                                'gau': Output_Module_Gau},
+                 add_linear_layer=True,
+                 sample_factor_rna=True,
+                 feature_factor_rna=False,
+                 sample_factor_atac=False,
+                 feature_factor_atac=False,
+                 zero_inflated=True,
+                 dispersion="feature-cell",
+                 infer_library_size_rna=False,
+                 infer_library_size_atac=True,
+                 mapping_module=Module_Module,
+                 mapping_hidden_nodes=None,
+                 mapping_learning_rate=1e-3,
+                 mapping_non_neg=False,
+                 mapping_layernorm=False,
+                 mapping_batchnorm=False,
+                 mapping_activation=nn.LeakyReLU(),
+                 mapping_dropout_rate=0,
+                 use_mixed_precision=False,
+                 gradient_checkpointing=True,
+                 pin_memory=True,
+                 memory_efficient_loading=True,
+                 val_chunk=4096,
+                 verbose=True,
+                 grad_sync=None):
+        self.scobj = scobj
+        self.modalities = modalities
+        self.modality_names = list(modalities.keys())
+        self.modality_distributions = list(modalities.values())
+        self.cov = cov
+        self.SEED = SEED
+        self.hidden_layer = hidden_layer
+        self.dropout_rate = dropout_rate
+        self.batchnorm = batchnorm
+        self.layernorm = layernorm
+        self.learning_rate_prediction = learning_rate_prediction
+        self.mapping_learning_rate = mapping_learning_rate
+        self.batch_size = batch_size
+        self.L2_lambda = L2_lambda
+        self.max_epochs = max_epochs
+        self.activation = activation
+        self.early_stopping_activation = early_stopping_activation
+        self.early_stopping_patience = early_stopping_patience
+        self.weight_decay = weight_decay
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.device = torch.device(device)
+        self.save_model = save_model
+        self.save_path = save_path
+        self.input_module = input_module
+        self.output_module = output_module
+        self.add_linear_layer = add_linear_layer
+        self.sample_factor_rna = sample_factor_rna
+        self.feature_factor_rna = feature_factor_rna
+        self.sample_factor_atac = sample_factor_atac
+        self.feature_factor_atac = feature_factor_atac
+        self.zero_inflated = zero_inflated
+        self.dispersion = dispersion
+        self.infer_library_size_rna = infer_library_size_rna
+        self.infer_library_size_atac = infer_library_size_atac
+        self.mapping_module = mapping_module
+        self.mapping_hidden_nodes = mapping_hidden_nodes
+        self.mapping_non_neg = mapping_non_neg
+        self.mapping_layernorm = mapping_layernorm
+        self.mapping_batchnorm = mapping_batchnorm
+        self.mapping_activation = mapping_activation
+        self.mapping_dropout_rate = mapping_dropout_rate
+        self.use_mixed_precision = use_mixed_precision     # reference: fp16 autocast; here: bf16 MFMA inputs
+        self.gradient_checkpointing = gradient_checkpointing
+        self.pin_memory = pin_memory
+        self.memory_efficient_loading = memory_efficient_loading
+        self.val_chunk = int(val_chunk)
+        self.verbose = verbose
+        self.grad_sync = grad_sync          # data-parallel hook (scpair_amd.distributed.GradSync) or None
+        self.scaler = None
+        self.history = {}
+        if self.add_linear_layer is True and self.mapping_non_neg is True:
+            raise ValueError('add_linear_layer and mapping_non_neg cannot be both True')
+        if self.sample_factor_rna is False and self.infer_library_size_rna is False:
+            raise ValueError('at leaset one of sample_factor_rna and infer_library_size_rna should be True')
+        if self.sample_factor_rna is True and self.infer_library_size_rna is True:
+            raise ValueError('sample_factor_rna and infer_library_size_rna cannot be both True')
+
+    # -- helpers -----------------------------------------------------------------------------------------
+    def _say(self, *a):
+        if self.verbose:
+            print(*a)
+
+    def _precision(self):
+        ops.set_precision("bf16" if self.use_mixed_precision else "fp32")
+
+    def _other(self, modality):
+        return [mn for mn in self.modality_names if mn != modality][0]
+
+    def _cov_dev(self, d, key):
+        v = d.get(key)
+        return None if (v is None or self.cov is None) else v.to(self.device).float()
+
+    def data_loader_builder(self):
+        """model.py:450-516 needs an AnnData object (anndata is not part of this build).  Build the three
+        '{modality}_{split}_mtx|_cov|_lib' dicts yourself (dense tensors, scipy CSR or DeviceCSR values) and call
+        train_predicting_networks(train, val, test) -- the seam the reference itself exposes."""
+        raise NotImplementedError(self.data_loader_builder.__doc__)
+
+    def set_data(self, train_data_dict, val_data_dict, test_data_dict=None):
+        """Registers the split dicts (what data_loader_builder() stores at model.py:512-516)."""
+        self.data_loader_dict_train, self.data_loader_dict_val = train_data_dict, val_data_dict
+        if test_data_dict is not None:
+            self.data_loader_dict_test = test_data_dict
+        for split, d in (("train", train_data_dict), ("val", val_data_dict), ("test", test_data_dict)):
+            if d is None:
+                continue
+            k = f"{self.modality_names[0]}_{split}_mtx"
+            n = d[k].shape[0]
+            if not hasattr(self, f"{split}_metadata") or getattr(self, f"{split}_metadata") is None:
+                setattr(self, f"{split}_metadata", _Index(n))
+        self._csr_cache = {}
+
+    def _csr(self, d, key):
+        cache = self.__dict__.setdefault("_csr_cache", {})
+        ck = (id(d), key)
+        if ck not in cache:
+            cache[ck] = _to_csr(d[key], self.device)
+        return cache[ck]
+
+    def run(self):
+        self.encoder_dict, self.decoder_dict = self.train_predicting_networks(*self.data_loader_builder())
+        low_dim_embeddings, _ = self.reference_embeddings()
+        self.mapping_dict = self.train_bidirectional_mapping()
+        low_dim_embeddings_mapped, _ = self.mapped_embeddings()
+        return self.encoder_dict, self.decoder_dict, self.mapping_dict, low_dim_embeddings, low_dim_embeddings_mapped
+
+    def get_scheduler(self, optimizer):
+        """model.py:592-602 ('ExponentialLR' and 'ReduceLROnPlateau' are broken upstream; 'StepLR' works)."""
+        if self.weight_decay == 'StepLR':
+            return torch.optim.lr_scheduler.StepLR(optimizer=optimizer, step_size=25, gamma=0.1, last_epoch=-1)
+        if self.weight_decay == 'ExponentialLR':
+            return torch.optim.lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=0.99, last_epoch=-1)
+        if self.weight_decay == 'ReduceLROnPlateau':
+            return torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer=optimizer, mode='min', factor=0.1, patience=10)
+        return None
+
+    # -- inference in chunks (the reference runs whole splits through one forward, model.py:539, 777) -----
+    @torch.no_grad()
+    def _encode(self, encoder, csr, cov, want_lib=False):
+        encoder.eval()
+        reps, libs = [], []
+        n = csr.n_rows
+        for r0 in range(0, n, self.val_chunk):
+            rows = np.arange(r0, min(n, r0 + self.val_chunk))
+            t = BatchTiles(csr, rows, want_lib=False)
+            rep, lat = encoder(t, None if cov is None else cov[r0:r0 + len(rows)])
+            reps.append(rep)
+            if lat is not None:
+                libs.append(lat)
+        rep = torch.cat(reps, 0)
+        if want_lib:
+            return rep, (torch.cat(libs, 0) if libs else None)
+        return rep
+
+    @torch.no_grad()
+    def _eval_split(self, encoder, decoder, xcsr, ycsr, cov, use_lib, likelihood):
+        """Full-split validation loss = sum(chunk_loss * chunk_count) / sum(count): identical to the reference's
+        single full-split mean (model.py:777)."""
+        evaluating_mode(encoder, decoder)
+        n = xcsr.n_rows
+        num = torch.zeros((), dtype=torch.float64, device=self.device)
+        den = torch.zeros((), dtype=torch.float64, device=self.device)
+        for r0 in range(0, n, self.val_chunk):
+            rows = np.arange(r0, min(n, r0 + self.val_chunk))
+            tx = BatchTiles(xcsr, rows, want_lib=False)
+            ty = BatchTiles(ycsr, rows, want_lib=True)
+            c = None if cov is None else cov[r0:r0 + len(rows)]
+            lib = ty.lib.reshape(-1, 1) if use_lib else None
+            if likelihood == "gau":
+                loss = eval_net(tx, ycsr.to_dense(rows).to(self.device), lib, encoder, decoder, likelihood,
+                                add_cov=c is not None, input_batch=c, output_batch=c)
+                cnt = torch.tensor(float(len(rows) * ycsr.n_cols), dtype=torch.float64, device=self.device)
+            else:
+                loss = eval_net(tx, ty, lib, encoder, decoder, likelihood, add_cov=c is not None, input_batch=c,
+                                output_batch=c)
+                cnt = float(len(rows) * ycsr.n_cols) - (ty.nnan.double()[0] if likelihood == "ber" else 0.0)
+                cnt = torch.as_tensor(cnt, dtype=torch.float64, device=self.device)
+            num += loss.double() * cnt
+            den += cnt
+        if self.grad_sync is not None:
+            num, den = self.grad_sync.reduce_scalars(num, den)
+        return num / den
+
+    def reference_embeddings(self):
+        """model.py:527-542."""
+        import pandas as pd
+        embeddings, df_embeddings = {}, {}
+        self._precision()
+        for modality in self.modality_names:
+            encoder_cal = self.encoder_dict[modality + ' to ' + self._other(modality)]
+            encoder_cal.eval().to(self.device)
+            for split in ['train', 'val', 'test']:
+                if hasattr(self, f'data_loader_dict_{split}'):
+                    d = getattr(self, f'data_loader_dict_{split}')
+                    cov = self._cov_dev(d, f'{modality}_{split}_cov')
+                    emb = self._encode(encoder_cal, self._csr(d, f'{modality}_{split}_mtx'), cov)
+                    embeddings[f'{modality}_{split}'] = emb.cpu().detach()
+                    df_embeddings[f'{modality}_{split}'] = pd.DataFrame(
+                        embeddings[f'{modality}_{split}'].numpy(), index=getattr(self, f'{split}_metadata').index)
+        self.embeddings = embeddings
+        return embeddings, df_embeddings
+
+    def mapped_embeddings(self):
+        """model.py:543-557."""
+        import pandas as pd
+        mapped_embeddings, df_mapped_embeddings = {}, {}
+        self._precision()
+        for input_modality in self.modality_names:
+            output_modality = self._other(input_modality)
+            mapping_network = self.mapping_dict[input_modality + '_to_' + output_modality]
+            mapping_network.eval().to(self.device)
+            for split in ['train', 'val', 'test']:
+                if hasattr(self, f'data_loader_dict_{split}'):
+                    key = f'{input_modality} to {output_modality}_{split}'
+                    with torch.no_grad():
+                        mapped_embeddings[key] = mapping_network(
+                            self.embeddings[input_modality + f'_{split}'].to(self.device)).cpu().detach()
+                    df_mapped_embeddings[key] = pd.DataFrame(mapped_embeddings[key].numpy(),
+                                                             index=getattr(self, f'{split}_metadata').index)
+        return mapped_embeddings, df_mapped_embeddings
+
+    @torch.no_grad()
+    def predict(self):
+        """model.py:558-591: decoder outputs [0] for every split (dense numpy arrays), lib = [1]."""
+        predictions = {}
+        self._precision()
+        for input_modality in self.modality_names:
+            output_modality = self._other(input_modality)
+            dist = self.modalities[output_modality]
+            decoder_cal = self.decoder_dict[input_modality + ' to ' + output_modality]
+            decoder_cal.eval().to(self.device)
+            need_lat = dist in ['ber', 'nb', 'zinb'] and (
+                (output_modality == 'Peaks' and self.infer_library_size_atac) or
+                (output_modality == 'Gene Expression' and self.infer_library_size_rna))
+            encoder_cal = None
+            if need_lat:
+                encoder_cal = self.encoder_dict[input_modality + ' to ' + output_modality]
+                encoder_cal.eval().to(self.device)
+            for split in ['train', 'val', 'test']:
+                if not hasattr(self, f'data_loader_dict_{split}'):
+                    continue
+                d = getattr(self, f'data_loader_dict_{split}')
+                emb = self.embeddings[input_modality + f'_{split}'].to(self.device)
+                ocov = self._cov_dev(d, f'{output_modality}_{split}_cov')
+                lat = None
+                if need_lat:
+                    icov = self._cov_dev(d, f'{input_modality}_{split}_cov')
+                    _, lat = self._encode(encoder_cal, self._csr(d, f'{input_modality}_{split}_mtx'), icov, want_lib=True)
+                lib = torch.ones(1, device=self.device) if dist in ['ber', 'nb', 'zinb'] else None
+                outs = []
+                for r0 in range(0, emb.shape[0], self.val_chunk):
+                    sl = slice(r0, r0 + self.val_chunk)
+                    pred = decoder_cal(emb[sl], None if ocov is None else ocov[sl], lib, None if lat is None else lat[sl])
+                    outs.append((pred if dist == 'gau' else pred[0]).cpu())
+                predictions[output_modality + f"_{split}"] = torch.cat(outs, 0).numpy()
+        return predictions
+
+    # -- training ------------------------------------------------------------------------------------------
+    def _build_predictor(self, input_modality, output_modality, in_dim, out_dim, n_cov):
+        """model.py:618-694: same construction / seeding order, so initial weights equal the reference's."""
+        dist = self.modalities[output_modality]
+        if self.modalities[input_modality] not in ['zinb', 'nb', 'ber', 'gau'] or dist not in ['zinb', 'nb', 'ber', 'gau']:
+            raise ValueError('scPair distribution should be one of the following: zinb, nb, ber, gau')
+        set_seed(self.SEED)
+        encoder = self.input_module(input_dim=in_dim, input_batch_num=n_cov, hidden_layer=self.hidden_layer,
+                                    activation=self.activation, layernorm=self.layernorm, batchnorm=self.batchnorm,
+                                    dropout_rate=self.dropout_rate, add_linear_layer=self.add_linear_layer,
+                                    infer_library_size=(self.infer_library_size_rna if output_modality == 'Gene Expression'
+                                                        else self.infer_library_size_atac))
+        use_lib = False
+        if dist == 'gau':
+            set_seed(self.SEED)
+            encoder = self.input_module(input_dim=in_dim, input_batch_num=n_cov, hidden_layer=self.hidden_layer,
+                                        activation=self.activation, layernorm=self.layernorm, batchnorm=self.batchnorm,
+                                        dropout_rate=self.dropout_rate, add_linear_layer=self.add_linear_layer,
+                                        infer_library_size=False)
+            set_seed(self.SEED)
+            decoder = self.output_module[dist](output_dim=out_dim, output_batch_num=n_cov, hidden_layer=self.hidden_layer,
+                                               infer_library_size=False, feature_factor=False)
+        elif dist in ['zinb', 'nb']:
+            set_seed(self.SEED)
+            decoder = self.output_module[dist](output_dim=out_dim, output_batch_num=n_cov, hidden_layer=self.hidden_layer,
+                                               infer_library_size=self.infer_library_size_rna,
+                                               sample_factor=self.sample_factor_rna, feature_factor=self.feature_factor_rna,
+                                               zero_inflated=self.zero_inflated, dispersion=self.dispersion)
+            use_lib = self.sample_factor_rna is True
+        else:
+            set_seed(self.SEED)
+            decoder = self.output_module[dist](output_dim=out_dim, output_batch_num=n_cov, hidden_layer=self.hidden_layer,
+                                               infer_library_size=self.infer_library_size_atac,
+                                               sample_factor=self.sample_factor_atac, feature_factor=self.feature_factor_atac)
+            use_lib = self.sample_factor_atac is True
+        encoder.apply(init_weights).to(self.device)
+        decoder.apply(init_weights).to(self.device)
+        return encoder, decoder, use_lib
+
+    def _make_optimizer(self, encoder, decoder):
+        """model.py:696-701: four AdamW groups."""
+        decay_e, nodecay_e, _, _ = add_weight_decay(encoder, output_layer=['output'])
+        decay_d, nodecay_d, _, _ = add_weight_decay(decoder, output_layer=['output'])
+        lr = self.learning_rate_prediction
+        groups = [{'params': decay_e, 'weight_decay': self.L2_lambda, 'lr': lr},
+                  {'params': decay_d, 'weight_decay': self.L2_lambda, 'lr': lr},
+                  {'params': nodecay_e, 'weight_decay': 0, 'lr': lr},
+                  {'params': nodecay_d, 'weight_decay': 0, 'lr': lr}]
+        return ops.FusedAdamW([g for g in groups if len(g['params']) > 0])
+
+    def train_predicting_networks(self, train_data_dict, val_data_dict, test_data_dict, batch_replay=None):
+        """model.py:603-812.  `batch_replay`: optional {direction_index: [row-id arrays]} to replay a recorded batch
+        order (parity tests); otherwise batches come from a DataLoader over row ids driven by the global torch RNG
+        exactly like the reference's."""
+        if self.device.type != "cuda":
+            raise RuntimeError("scpair_amd trains on a GPU only (device must be cuda); there is no CPU path")
+        self._precision()
+        self.set_data(train_data_dict, val_data_dict, test_data_dict)
+        encoder_dict, decoder_dict = {}, {}
+        for di, input_modality in enumerate(self.modalities.keys()):
+            output_modality = self._other(input_modality)
+            prediction_order = {'input': input_modality, 'output': output_modality}
+            self._say('Set up predicting networks:', prediction_order)
+            xtr = self._csr(train_data_dict, input_modality + '_train_mtx')
+            ytr = self._csr(train_data_dict, output_modality + '_train_mtx')
+            xva = self._csr(val_data_dict, input_modality + '_val_mtx')
+            yva = self._csr(val_data_dict, output_modality + '_val_mtx')
+            ctr = self._cov_dev(train_data_dict, input_modality + '_train_cov')
+            cva = self._cov_dev(val_data_dict, input_modality + '_val_cov')
+            n_cov = 0 if ctr is None else ctr.shape[1]
+            dist = self.modalities[output_modality]
+            encoder, decoder, use_lib = self._build_predictor(input_modality, output_modality, xtr.n_cols, ytr.n_cols, n_cov)
+            optimizer = self._make_optimizer(encoder, decoder)
+            scheduler = self.get_scheduler(optimizer)
+            if self.grad_sync is not None:
+                self.grad_sync.broadcast(list(encoder.parameters()) + list(decoder.parameters()) +
+                                         list(encoder.buffers()) + list(decoder.buffers()))
+            set_seed(self.SEED)
+            loader = _index_loader(xtr.n_rows, self.batch_size) if batch_replay is None else None
+            ytr_dense = ytr.to_dense().to(self.device) if dist == 'gau' else None
+            if not self.early_stopping_activation:
+                raise TypeError("early_stopping_activation=False is unusable upstream (model.py:719, 786: "
+                                "`val < None`); keep it True")
+            patience, no_improve, min_val = self.early_stopping_patience, 0, np.inf
+            hist = {"train_loss": [], "val_loss": []}
+            replay = None if batch_replay is None else list(batch_replay[di])
+            per_epoch = None if replay is None else int(np.ceil(xtr.n_rows / self.batch_size))
+            encoder_ckpt = decoder_ckpt = None
+            for epoch in range(self.max_epochs):
+                training_mode(encoder, decoder)
+                if replay is not None:
+                    batches = replay[epoch * per_epoch:(epoch + 1) * per_epoch]
+                    if not batches:
+                        break
+                else:
+                    batches = (b[0].numpy() for b in loader)
+                step_losses = []
+                for rows in batches:
+                    if self.grad_sync is not None:
+                        rows = self.grad_sync.shard(rows)
+                    tx = BatchTiles(xtr, rows, want_lib=False)
+                    c = None if ctr is None else ctr[torch.as_tensor(rows, device=self.device)]
+                    if dist == 'gau':
+                        ty, lib = ytr_dense[torch.as_tensor(rows, device=self.device)], None
+                    else:
+                        ty = BatchTiles(ytr, rows, want_lib=use_lib)
+                        lib = ty.lib.reshape(-1, 1) if use_lib else None
+                    loss = self._train_step(tx, ty, lib, encoder, decoder, optimizer, dist, c)
+                    step_losses.append(loss)
+                hist["train_loss"].extend(step_losses)
+                val_total_loss = float(self._eval_split(encoder, decoder, xva, yva, cva, use_lib, dist).item())
+                hist["val_loss"].append(val_total_loss)
+                if scheduler is not None and optimizer.param_groups[0]['lr'] > 1e-7:
+                    scheduler.step()
+                if val_total_loss < min_val:
+                    no_improve, min_val = 0, val_total_loss
+                    encoder_ckpt, decoder_ckpt = copy.deepcopy(encoder), copy.deepcopy(decoder)
+                else:
+                    no_improve += 1
+                self._say(f"[{input_modality} -> {output_modality}] epoch {epoch + 1} validation loss {val_total_loss:.6f}")
+                if epoch > 1 and no_improve == patience:
+                    self._say("Early Stopped!")
+                    break
+            hist["train_loss"] = [float(v) for v in torch.stack(hist["train_loss"]).cpu()] if hist["train_loss"] else []
+            key = input_modality + ' to ' + output_modality
+            self.history[key] = hist
+            encoder_dict[key] = copy.deepcopy(encoder_ckpt.eval())
+            decoder_dict[key] = copy.deepcopy(decoder_ckpt.eval())
+            if self.save_model is True:
+                if self.save_path is None:
+                    self.save_path = os.getcwd()
+                torch.save(encoder_dict[key], self.save_path + '/encoder_' + input_modality + '_to_' + output_modality + '.pt')
+                torch.save(decoder_dict[key], self.save_path + '/decoder_' + input_modality + '_to_' + output_modality + '.pt')
+            self._say(f"Completed training for {input_modality} to {output_modality}")
+        self.encoder_dict, self.decoder_dict = encoder_dict, decoder_dict
+        return encoder_dict, decoder_dict
+
+    def _train_step(self, tx, ty, lib, encoder, decoder, optimizer, dist, cov):
+        if self.grad_sync is None:
+            return train_net(tx, ty, lib, encoder, decoder, optimizer, likelihood_type=dist, add_cov=cov is not None,
+                             input_batch=cov, output_batch=cov)
+        from .utils import _predictor_loss
+        loss = _predictor_loss(tx, ty, lib, encoder, decoder, dist, cov is not None, cov, cov)
+        optimizer.zero_grad()
+        loss.backward()
+        # weight of this rank's mean in the global-batch mean = its share of the valid label elements
+        n_valid = float(ty.shape[0] * ty.shape[1]) if not isinstance(ty, BatchTiles) or dist != "ber" else \
+            (float(ty.B * ty.F) - ty.nnan.double()[0])
+        self.grad_sync.all_reduce_grads([p for g in optimizer.param_groups for p in g['params']], n_valid)
+        optimizer.step()
+        return self.grad_sync.weighted_mean(loss.detach(), n_valid)
+
+    def train_bidirectional_mapping(self):
+        """model.py:813-924."""
+        self._precision()
+        embedding_dim = self.hidden_layer[-1]
+        mapping_dict = {}
+        for input_modality in self.modality_names:
+            output_modality = self._other(input_modality)
+            self._say('mapping direction:', input_modality, 'to', output_modality)
+            xin = self.embeddings[input_modality + '_train'].to(self.device)
+            yout = self.embeddings[output_modality + '_train'].to(self.device)
+            xva = self.embeddings[input_modality + '_val'].to(self.device)
+            yva = self.embeddings[output_modality + '_val'].to(self.device)
+            set_seed(self.SEED)
+            loader = _index_loader(xin.shape[0], self.batch_size)
+            mapping_network = self.mapping_module(origin_module_dim=embedding_dim, target_module_dim=embedding_dim,
+                                                  translational_hidden_nodes=self.mapping_hidden_nodes,
+                                                  non_neg=self.mapping_non_neg, activation=self.mapping_activation,
+                                                  layernorm=self.mapping_layernorm, batchnorm=self.mapping_batchnorm,
+                                                  dropout_rate=self.mapping_dropout_rate)
+            mapping_network.apply(init_weights).to(self.device)
+            decay_param, nodecay_param, _, _ = add_weight_decay(mapping_network, output_layer="bias")
+            groups = [{'params': decay_param, 'weight_decay': self.L2_lambda, 'lr': self.mapping_learning_rate},
+                      {'params': nodecay_param, 'weight_decay': 0, 'lr': self.mapping_learning_rate}]
+            optimizer = ops.FusedAdamW([g for g in groups if len(g['params']) > 0])
+            scheduler = self.get_scheduler(optimizer)
+            patience, no_improve, min_val = self.early_stopping_patience, 0, np.inf
+            hist = {"train_loss": [], "val_loss": []}
+            ckpt = None
+            for epoch in range(self.max_epochs):
+                mapping_network.train()
+                for (idx,) in loader:
+                    idx = idx.to(self.device)
+                    pred_emb = mapping_network(xin[idx])
+                    training_loss = scaled_loss(yout[idx], pred_emb)
+                    optimizer.zero_grad()
+                    training_loss.backward()
+                    optimizer.step()
+                    hist["train_loss"].append(training_loss.detach())
+                mapping_network.eval()
+                with torch.no_grad():
+                    val_total_loss = float(scaled_loss(yva, mapping_network(xva)).item())
+                hist["val_loss"].append(val_total_loss)
+                if scheduler is not None and optimizer.param_groups[0]['lr'] > 1e-7:
+                    scheduler.step()
+                if val_total_loss < min_val:
+                    no_improve, min_val = 0, val_total_loss
+                    ckpt = copy.deepcopy(mapping_network)
+                else:
+                    no_improve += 1
+                if epoch > 1 and no_improve == patience:
+                    self._say("Early Stopped!")
+                    break
+            hist["train_loss"] = [float(v) for v in torch.stack(hist["train_loss"]).cpu()] if hist["train_loss"] else []
+            key = input_modality + '_to_' + output_modality
+            self.history[key] = hist
+            mapping_dict[key] = copy.deepcopy(ckpt)
+            if self.save_model is True:
+                if self.save_path is None:
+                    self.save_path = os.getcwd()
+                torch.save(mapping_dict[key], self.save_path + '/mapping_' + input_modality + '_to_' + output_modality + '.pt')
+            self._say(f"Completed mapping training for {input_modality} to {output_modality}")
+        self.mapping_dict = mapping_dict
+        return mapping_dict
+
+    def augment(self, unimodal_scobj, unimodal_modalities, unimodal_cov=None):
+        """model.py:925-1036: fine-tune a copy of the trained encoder on unimodal cells to regress its own embeddings
+        (dropout active), early-stopped on the bimodal train+val cells.  `unimodal_scobj` needs `.X` (scipy sparse,
+        ndarray or DeviceCSR); covariates other than None/None are not supported without AnnData."""
+        self._precision()
+        self.unimodal_scobj, self.unimodal_modalities, self.unimodal_cov = unimodal_scobj, unimodal_modalities, unimodal_cov
+        self.unimodal_modality_names = list(unimodal_modalities.keys())
+        if not set(self.unimodal_modality_names).issubset(self.modalities.keys()):
+            raise ValueError('Unimodal data should have the same modality as one of the multimodal data')
+        if self.cov is not None or unimodal_cov is not None:
+            raise NotImplementedError("augment() with covariates needs the AnnData plumbing (model.py:936-947)")
+        name = self.unimodal_modality_names[0]
+        other = [mn for mn in self.modalities.keys() if mn != name][0]
+        X = unimodal_scobj.X if hasattr(unimodal_scobj, "X") else unimodal_scobj
+        uni = _to_csr(X, self.device)
+        btr = self._csr(self.data_loader_dict_train, name + '_train_mtx')
+        bva = self._csr(self.data_loader_dict_val, name + '_val_mtx')
+        bte = self._csr(self.data_loader_dict_test, name + '_test_mtx') if hasattr(self, 'data_loader_dict_test') else None
+        enc = copy.deepcopy(self.encoder_dict[name + ' to ' + other]).to(self.device)
+        enc.eval()
+        uni_label = self._encode(enc, uni, None)
+        btr_label, bva_label = self._encode(enc, btr, None), self._encode(enc, bva, None)
+        set_seed(self.SEED)
+        loader = _index_loader(uni.n_rows, self.batch_size)
+        optimizer = ops.FusedAdamW(enc.parameters(), lr=self.learning_rate_prediction, weight_decay=self.L2_lambda)
+        patience, no_improve, min_val = self.early_stopping_patience, 0, np.inf
+        self.augment_encoder_ckpt = None
+        for epoch in range(self.max_epochs):
+            enc.train()
+            for (idx,) in loader:
+                rows = idx.numpy()
+                pred = enc(BatchTiles(uni, rows, want_lib=False), None)[0]
+                loss = scaled_loss(uni_label[idx.to(self.device)], pred)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+            with torch.no_grad():
+                pv = torch.cat([self._encode(enc, btr, None), self._encode(enc, bva, None)], 0)
+                val_total_loss = float(scaled_loss(torch.cat([btr_label, bva_label], 0), pv).item())
+            if val_total_loss < min_val:
+                no_improve, min_val = 0, val_total_loss
+                self.augment_encoder_ckpt = copy.deepcopy(enc)
+            else:
+                no_improve += 1
+            if epoch > 1 and no_improve == patience:
+                self._say("Early Stopped!")
+                break
+        self.augment_encoder_ckpt.eval()
+        if self.save_model is True:
+            if self.save_path is None:
+                self.save_path = os.getcwd()
+            torch.save(self.augment_encoder_ckpt, self.save_path + '/augment_encoder_' + name + '_to_' + other + '.pt')
+        self.augment_encoder_dict = {'scPair_augment: ' + name + ' to ' + other: copy.deepcopy(self.augment_encoder_ckpt)}
+        augment_emb = {}
+        for split, csr in (('unimodal_train', uni), ('bimodal_train', btr), ('bimodal_val', bva), ('bimodal_test', bte)):
+            if csr is None:
+                continue
+            augment_emb[name + f'_{split}'] = self._encode(self.augment_encoder_ckpt, csr, None).cpu().numpy()
+        return self.augment_encoder_dict, augment_emb

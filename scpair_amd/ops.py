@@ -366,7 +366,6 @@ class ReparamKlFn(torch.autograd.Function):
         _lib.check(L.scp_reparam_kl_fwd(mu.data_ptr(), sraw.data_ptr(), eps.data_ptr(), n, sigma.data_ptr(), z.data_ptr(),
                                         kl.data_ptr(), ws.data_ptr(), _lib.stream()), "scp_reparam_kl_fwd")
         ctx.save_for_backward(mu, sraw, eps, sigma)
-        ctx.mark_non_differentiable(sigma)
         return sigma, z, kl.reshape(())
 
     @staticmethod
@@ -380,6 +379,9 @@ class ReparamKlFn(torch.autograd.Function):
         _lib.check(L.scp_reparam_kl_bwd(mu.data_ptr(), sraw.data_ptr(), eps.data_ptr(), sigma.data_ptr(), _lib.ptr(dzc),
                                         None, _lib.ptr(gk), n, dmu.data_ptr(), dsraw.data_ptr(), _lib.stream()),
                    "scp_reparam_kl_bwd")
+        if _dsigma is not None:
+            # a caller differentiating through the returned sigma itself (e.g. its own KL from mu, sigma)
+            dsraw = dsraw + _dsigma * torch.where(sraw > 20, torch.ones_like(sraw), torch.sigmoid(sraw))
         return dmu, dsraw, None
 
 
@@ -458,3 +460,85 @@ class FusedAdamW(torch.optim.Optimizer):
             arr = (_lib.AdamTensor * len(descs))(*descs)
             _lib.check(L.scp_adamw_multi(arr, len(descs), b1, b2, eps, _lib.stream()), "scp_adamw_multi")
         return loss
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone likelihoods on dense tensors (the reference's own call form)
+# ------------------------------------------------------------------------------------------------
+class BceMaskedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        L = _lib.lib()
+        x, p = _f32c(x), _f32c(p)
+        _lib.require_cuda(x, p)
+        if x.shape != p.shape:
+            raise ValueError("binarized_loss: shape mismatch")
+        n = x.numel()
+        lc = torch.empty(2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(520, dtype=torch.float64, device=x.device)
+        _lib.check(L.scp_bce_masked_fwd(x.data_ptr(), p.data_ptr(), n, lc.data_ptr(), ws.data_ptr(), _lib.stream()),
+                   "scp_bce_masked_fwd")
+        ctx.save_for_backward(x, p, lc)
+        return lc[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x, p, lc = ctx.saved_tensors
+        g = _f32c(g).reshape(1)
+        dp = torch.empty_like(p)
+        _lib.check(L.scp_bce_masked_bwd(x.data_ptr(), p.data_ptr(), x.numel(), lc.data_ptr(), g.data_ptr(),
+                                        dp.data_ptr(), _lib.stream()), "scp_bce_masked_bwd")
+        return None, dp
+
+
+def bce_masked(x, p):
+    return BceMaskedFn.apply(x, p)
+
+
+class NbLogLikFn(torch.autograd.Function):
+    """Element-wise log NB / ZINB likelihood (scVI_distribution.py:29-105); pi=None selects NB."""
+
+    @staticmethod
+    def forward(ctx, x, mu, theta, pi):
+        L = _lib.lib()
+        x, mu = _f32c(x), _f32c(mu)
+        _lib.require_cuda(x, mu, theta, pi)
+        shape = torch.broadcast_shapes(x.shape, mu.shape, theta.shape, *(() if pi is None else (pi.shape,)))
+        cols = shape[-1]
+        theta_vec = theta.ndim == 1 and theta.numel() == cols and len(shape) > 1
+        xe = _f32c(x.expand(shape)); me = _f32c(mu.expand(shape))
+        te = _f32c(theta) if theta_vec else _f32c(theta.expand(shape))
+        pe = None if pi is None else _f32c(pi.expand(shape))
+        n = xe.numel()
+        out = torch.empty(shape, dtype=torch.float32, device=xe.device)
+        _lib.check(L.scp_nbll_fwd(xe.data_ptr(), me.data_ptr(), te.data_ptr(), int(theta_vec), cols, _lib.ptr(pe), n,
+                                  out.data_ptr(), _lib.stream()), "scp_nbll_fwd")
+        ctx.save_for_backward(xe, me, te, pe)
+        ctx.meta = (theta_vec, cols, mu.shape, theta.shape, None if pi is None else pi.shape)
+        if theta_vec:
+            out = out.reshape((1,) * 0 + tuple(shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        xe, me, te, pe = ctx.saved_tensors
+        theta_vec, cols, mu_shape, th_shape, pi_shape = ctx.meta
+        g = _f32c(g.expand(xe.shape))
+        n = xe.numel()
+        dmu, dth = torch.empty_like(xe), torch.empty_like(xe)
+        dpi = torch.empty_like(xe) if pe is not None else None
+        _lib.check(L.scp_nbll_bwd(xe.data_ptr(), me.data_ptr(), te.data_ptr(), int(theta_vec), cols, _lib.ptr(pe),
+                                  g.data_ptr(), n, dmu.data_ptr(), dth.data_ptr(), _lib.ptr(dpi), _lib.stream()),
+                   "scp_nbll_bwd")
+
+        def unb(t, shape):
+            if t is None or shape is None:
+                return None
+            return t.sum_to_size(shape) if tuple(t.shape) != tuple(shape) else t
+        return None, unb(dmu, mu_shape), unb(dth, th_shape), unb(dpi, pi_shape)
+
+
+def nb_loglik(x, mu, theta, pi=None):
+    return NbLogLikFn.apply(x, mu, theta, pi)

@@ -21,7 +21,12 @@ class DeviceCSR:
         self.indptr_host = ip
         self.device = torch.device(device)
         self.indptr = torch.from_numpy(ip).to(self.device)
-        self.indices = torch.as_tensor(np.ascontiguousarray(np.asarray(indices, dtype=np.int32))).to(self.device)
+        idx = np.ascontiguousarray(np.asarray(indices, dtype=np.int32))
+        self.nnz = int(idx.shape[0])
+        if self.nnz == 0:                     # keep device pointers non-null for an all-zero matrix
+            idx = np.zeros(1, np.int32)
+            values = None if values is None else np.zeros(1, np.float32)
+        self.indices = torch.as_tensor(idx).to(self.device)
         self.values = None if values is None else torch.as_tensor(
             np.ascontiguousarray(np.asarray(values, dtype=np.float32))).to(self.device)
         if ip.shape[0] != self.shape[0] + 1:
@@ -66,8 +71,8 @@ class DeviceCSR:
         """Dense fp32 copy (tests / small inference only)."""
         ip = self.indptr_host
         n = self.shape[0]
-        idx = self.indices.cpu().numpy()
-        val = np.ones(idx.shape[0], np.float32) if self.values is None else self.values.cpu().numpy()
+        idx = self.indices.cpu().numpy()[: self.nnz]
+        val = np.ones(idx.shape[0], np.float32) if self.values is None else self.values.cpu().numpy()[: self.nnz]
         out = np.zeros(self.shape, np.float32)
         r = np.repeat(np.arange(n), np.diff(ip))
         out[r, idx] = val

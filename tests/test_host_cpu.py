@@ -1,0 +1,115 @@
+"""Host-side logic that needs no GPU: reference-identical construction/initialisation, parameter names,
+weight-decay grouping, batch order, argument validation, and the no-CPU-fallback rule."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import scpair_amd as S
+from tests import util as U
+
+
+def _obj(mods, zi, **kw):
+    return S.scPair_object(None, modalities=mods, cov=None, hidden_layer=[16, 8], dropout_rate=0.0, device="cpu",
+                           save_model=False, zero_inflated=zi, verbose=False, **kw)
+
+
+@pytest.mark.parametrize("name,mods,zi", [("traj_zinb_ber", {"Gene Expression": "zinb", "Peaks": "ber"}, True),
+                                          ("traj_nb_ber", {"Gene Expression": "nb", "Peaks": "ber"}, False)])
+def test_initial_weights_equal_reference(name, mods, zi):
+    """Same construction + seeding order as model.py:620-694 => bit-identical initial state_dicts."""
+    d = U.load(name)
+    o = _obj(mods, zi)
+    for di, (i, oo, a, b) in enumerate([("Gene Expression", "Peaks", 64, 128), ("Peaks", "Gene Expression", 128, 64)]):
+        enc, dec, _ = o._build_predictor(i, oo, a, b, 0)
+        gold_e, gold_d = U.sub(d, f"dir{di}/enc_init", tensor=False), U.sub(d, f"dir{di}/dec_init", tensor=False)
+        assert sorted(enc.state_dict()) == sorted(gold_e) and sorted(dec.state_dict()) == sorted(gold_d)
+        for k, v in enc.state_dict().items():
+            np.testing.assert_array_equal(v.numpy(), gold_e[k])
+        for k, v in dec.state_dict().items():
+            np.testing.assert_array_equal(v.numpy(), gold_d[k])
+
+
+def test_batch_order_equals_reference():
+    """The row-id DataLoader consumes the global torch RNG like the reference's DataLoader (model.py:712-717)."""
+    from scpair_amd.model import _index_loader
+    d = U.load("traj_nb_ber")
+    c = U.cfg(d, "cfg")
+    gold = U.split_batches(d["dir0/batch_rows"], d["dir0/batch_sizes"])
+    S.set_seed(0)
+    loader = _index_loader(len(d["emb/Gene Expression_train"]), c["batch"])
+    got = []
+    for _ in range(c["epochs"]):
+        got.extend(b[0].numpy() for b in loader)
+    assert len(got) == len(gold)
+    for a, b in zip(got, gold):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_weight_decay_groups_equal_reference():
+    with open(os.path.join(U.GOLD, "weight_decay_groups.json")) as f:
+        groups = json.load(f)
+    H, G, P = [16, 8], 32, 64
+    enc = S.Input_Module(input_dim=G, input_batch_num=0, hidden_layer=H, activation=nn.LeakyReLU(), layernorm=True,
+                         batchnorm=True, dropout_rate=0.1, add_linear_layer=True, infer_library_size=True)
+    raw = S.Output_Module_Raw(output_dim=G, output_batch_num=0, hidden_layer=H, infer_library_size=False,
+                              sample_factor=True, feature_factor=True, zero_inflated=True, dispersion="feature-cell")
+    ber = S.Output_Module_Ber(output_dim=P, output_batch_num=0, hidden_layer=H, infer_library_size=True,
+                              sample_factor=False, feature_factor=True)
+    gau = S.Output_Module_Gau(output_dim=G, output_batch_num=0, hidden_layer=H, infer_library_size=False, feature_factor=True)
+    mp = S.Module_Module(origin_module_dim=8, target_module_dim=8, translational_hidden_nodes=[12], non_neg=False,
+                         layernorm=True, activation=nn.LeakyReLU(), batchnorm=False, dropout_rate=0)
+    for key, mod, ol in [("Input_Module", enc, ["output"]), ("Output_Module_Raw", raw, ["output"]),
+                         ("Output_Module_Ber", ber, ["output"]), ("Output_Module_Gau", gau, ["output"]),
+                         ("Module_Module[bias]", mp, "bias")]:
+        _, _, dn, ndn = S.add_weight_decay(mod, output_layer=ol)
+        assert dn == groups[key]["decay"] and ndn == groups[key]["nodecay"], key
+        assert {k: v.ndim for k, v in mod.named_parameters()} == groups[key]["ndim"]
+
+
+def test_module_parameter_names_match_goldens():
+    d = U.load("mod_vae")
+    enc = S.VAE_ENCODER(32, 0, [16], 6, infer_library_size=True)
+    assert sorted(enc.state_dict()) == sorted(U.sub(d, "c1/enc_sd"))
+    dec = S.VAE_DECODER(32, 0, [16], 6, infer_library_size=False, distribution="zinb", dispersion="feature-cell")
+    assert sorted(dec.state_dict()) == sorted(k for k in U.sub(d, "c4/dec_sd"))
+    m = U.load("mod_gau_map")
+    mp = S.Module_Module(8, 8, [12, 10], non_neg=False, layernorm=False, batchnorm=True, activation=nn.LeakyReLU())
+    assert sorted(mp.state_dict()) == sorted(U.sub(m, "map3/sd"))
+
+
+def test_constructor_validation_like_reference():
+    with pytest.raises(ValueError):
+        S.scPair_object(None, add_linear_layer=True, mapping_non_neg=True, device="cpu")
+    with pytest.raises(ValueError):
+        S.scPair_object(None, sample_factor_rna=False, infer_library_size_rna=False, device="cpu")
+    with pytest.raises(ValueError):
+        S.scPair_object(None, sample_factor_rna=True, infer_library_size_rna=True, device="cpu")
+    dec = S.Output_Module_Raw(8, 0, [4], sample_factor=False)
+    with pytest.raises(Exception, match="library size is missing"):
+        dec.fused_loss(torch.zeros(2, 4), None, None, None, None, "nb")
+    with pytest.raises(NotImplementedError):
+        S.FCNN([4, 4], activation=nn.Tanh())(torch.zeros(1, 4))
+
+
+def test_no_cpu_fallback():
+    o = _obj({"Gene Expression": "nb", "Peaks": "ber"}, False)
+    with pytest.raises(RuntimeError, match="GPU"):
+        o.train_predicting_networks({}, {}, {})
+    with pytest.raises(RuntimeError):
+        S.scaled_loss(torch.zeros(3), torch.zeros(3))
+    src = open(os.path.join(os.path.dirname(S.__file__), "ops.py")).read() + \
+        open(os.path.join(os.path.dirname(S.__file__), "model.py")).read()
+    assert "oracle" not in src, "the product must never import the oracle"
+
+
+def test_synthetic_generator_is_deterministic():
+    a = S.synth.make_paired(64, 20, 30, seed=3, p_atac=0.1) if hasattr(S, "synth") else None
+    from scpair_amd import synth
+    a, b = synth.make_paired(64, 20, 30, seed=3, p_atac=0.1), synth.make_paired(64, 20, 30, seed=3, p_atac=0.1)
+    assert (a["rna"] != b["rna"]).nnz == 0 and (a["atac"] != b["atac"]).nnz == 0
+    assert a["rna"].has_canonical_format and a["atac"].has_canonical_format
+    assert len(set(a["train"]) | set(a["val"]) | set(a["test"])) == 64

@@ -342,7 +342,7 @@ def test_adamw_golden(S):
         opt.step()
         close(pa, d[f"p{s}_0"], rtol=1e-6, atol=1e-7); close(pb, d[f"p{s}_1"], rtol=1e-6, atol=1e-7)
     close(opt.state[pa]["exp_avg"], d["m_final_0"], rtol=1e-5, atol=1e-8)
-    close(opt.state[pa]["exp_avg_sq"], d["v_final_0"], rtol=1e-5, atol=1e-10)
+    close(opt.state[pa]["exp_avg_sq"], d["v_final_0"], rtol=5e-5, atol=1e-10)
     # large, oddly sized tensor vs torch.optim.AdamW on the CPU
     g = torch.Generator().manual_seed(1)
     p0 = torch.randn(100003, generator=g); gr = torch.randn(100003, generator=g)
