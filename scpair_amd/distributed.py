@@ -1,0 +1,84 @@
+"""Cell-sharded data parallelism: one process per GPU, gradients summed with a bucketed all-reduce
+(torch.distributed backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
+
+The reference has no distributed code; the semantics implemented here are those of its
+single-process loop with the GLOBAL batch: every loss is a mean over label elements (loss.py:26, 39-40, 48, 50), so
+the global-batch gradient is sum_r (n_r / n_total) * g_r where n_r is rank r's number of valid label elements.
+
+Buckets: tensors >= `big` elements are reduced in place one by one (the wide first-layer dW is produced last in
+backward and is the only exposed message); everything smaller is packed into one flat buffer per call.  All
+collectives are issued async and waited together, so they overlap with whatever the caller runs in between.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, group=None, big: int = 1 << 20):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.big = big
+        self._pending = []
+
+    # -- batch sharding --------------------------------------------------------------------------------------
+    def shard(self, rows):
+        """This rank's contiguous slice of a global batch (all ranks draw the same global batch order)."""
+        rows = np.asarray(rows)
+        return np.array_split(rows, self.world)[self.rank]
+
+    # -- collectives -----------------------------------------------------------------------------------------
+    def broadcast(self, tensors, src=0):
+        for t in tensors:
+            dist.broadcast(t.data if hasattr(t, "data") else t, src=src, group=self.group)
+
+    def start_all_reduce(self, grads):
+        """Issue async SUM all-reduces for `grads` (list of tensors); returns nothing, call finish()."""
+        small = [g for g in grads if g.numel() < self.big]
+        for g in grads:
+            if g.numel() >= self.big:
+                self._pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+        if small:
+            flat = torch.cat([g.reshape(-1) for g in small])
+            self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, small))
+
+    def finish(self):
+        for work, flat, small in self._pending:
+            work.wait()
+            if flat is not None:
+                o = 0
+                for g in small:
+                    n = g.numel()
+                    g.copy_(flat[o:o + n].view_as(g))
+                    o += n
+        self._pending = []
+
+    def all_reduce_grads(self, params, n_valid):
+        """Global-batch gradient: each rank scales its mean-gradient by n_r / n_total, then SUM all-reduce."""
+        dev = params[0].device
+        nv = torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(1).clone()
+        tot = nv.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        w = (nv / tot).to(torch.float32)
+        grads = [p.grad for p in params if p.grad is not None]
+        for g in grads:
+            g.mul_(w)
+        self.start_all_reduce(grads)
+        self.finish()
+
+    def weighted_mean(self, value, n_valid):
+        dev = value.device
+        v = torch.stack([value.double() * torch.as_tensor(n_valid, dtype=torch.float64, device=dev),
+                         torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(())])
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        return (v[0] / v[1]).to(value.dtype)
+
+    def reduce_scalars(self, num, den):
+        v = torch.stack([num.double(), den.double()])
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        return v[0], v[1]

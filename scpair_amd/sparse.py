@@ -35,6 +35,24 @@ class DeviceCSR:
             raise ValueError("more than 2^25 features are not supported by the tile-list key format")
 
     @classmethod
+    def from_device(cls, indptr, indices, values, shape):
+        """Wrap CSR arrays that already live in GPU memory (int64 indptr, int32 indices, fp32 values or None)."""
+        self = cls.__new__(cls)
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.device = indptr.device
+        self.indptr = indptr.to(torch.int64).contiguous()
+        self.indptr_host = self.indptr.cpu().numpy()
+        self.indices = indices.to(torch.int32).contiguous()
+        self.nnz = int(self.indices.shape[0])
+        self.values = None if values is None else values.to(torch.float32).contiguous()
+        if self.nnz == 0:
+            self.indices = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.values = None if values is None else torch.zeros(1, dtype=torch.float32, device=self.device)
+        if self.shape[1] >= (1 << 25):
+            raise ValueError("more than 2^25 features are not supported by the tile-list key format")
+        return self
+
+    @classmethod
     def from_scipy(cls, m, device="cuda", binary=False):
         """Canonical CSR required (duplicates summed, indices sorted): scipy's .sum_duplicates() does both."""
         import scipy.sparse as sp

@@ -71,3 +71,58 @@ def make_paired(n_cells: int, n_genes: int, n_peaks: int, seed: int = 0,
     atac = make_atac(n_cells, n_peaks, seed=seed + 1, p=p_atac)
     tr, va, te = split_indices(n_cells, seed)
     return {"rna": rna, "atac": atac, "train": tr, "val": va, "test": te}
+
+
+# ---- device-side generators for benchmark-scale inputs (same distributions, torch RNG on the GPU) ----------
+def make_atac_device(n_cells, n_peaks, device, seed=1, p=0.03, chunk=8192):
+    """Bernoulli(p) per entry, generated as a Bernoulli process (geometric gaps) directly in GPU memory."""
+    import torch
+    from .sparse import DeviceCSR
+    g = torch.Generator(device=device).manual_seed(seed)
+    m = int(n_peaks * p * 1.25) + 64
+    idx_chunks, counts = [], []
+    log1mp = float(np.log1p(-p))
+    for r0 in range(0, n_cells, chunk):
+        r = min(chunk, n_cells - r0)
+        u = torch.rand((r, m), generator=g, device=device).clamp_min_(1e-12)
+        gaps = torch.floor(torch.log(u) / log1mp).to(torch.int64) + 1          # Geometric(p) on {1,2,...}
+        cols = torch.cumsum(gaps, 1) - 1
+        keep = cols < n_peaks
+        counts.append(keep.sum(1))
+        idx_chunks.append(cols[keep].to(torch.int32))
+    counts = torch.cat(counts)
+    indptr = torch.zeros(n_cells + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    return DeviceCSR.from_device(indptr, torch.cat(idx_chunks), None, (n_cells, n_peaks))
+
+
+def make_rna_device(n_cells, n_genes, device, seed=0, shape_g=0.3, target_density=0.1, chunk=4096):
+    """Poisson(g_j * s_i) counts generated chunk-wise in GPU memory and compacted to CSR."""
+    import torch
+    from .sparse import DeviceCSR
+    rng = np.random.default_rng(seed)
+    gj = rng.gamma(shape_g, 1.0, size=n_genes)
+    si = rng.gamma(5.0, 0.2, size=n_cells)
+    if target_density is not None:
+        lo, hi = 1e-4, 1e3
+        for _ in range(40):
+            mid = np.sqrt(lo * hi)
+            dens = 1.0 - np.mean(np.exp(-np.outer(si[:256], gj * mid)))
+            lo, hi = (lo, mid) if dens > target_density else (mid, hi)
+        gj = gj * np.sqrt(lo * hi)
+    g = torch.Generator(device=device).manual_seed(seed)
+    gj_d = torch.tensor(gj, dtype=torch.float32, device=device)
+    si_d = torch.tensor(si, dtype=torch.float32, device=device)
+    idx_chunks, val_chunks, counts = [], [], []
+    for r0 in range(0, n_cells, chunk):
+        lam = si_d[r0:r0 + chunk, None] * gj_d[None, :]
+        x = torch.poisson(lam, generator=g)
+        nz = x > 0
+        counts.append(nz.sum(1))
+        rc = nz.nonzero()
+        idx_chunks.append(rc[:, 1].to(torch.int32))
+        val_chunks.append(x[nz])
+    counts = torch.cat(counts)
+    indptr = torch.zeros(n_cells + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    return DeviceCSR.from_device(indptr, torch.cat(idx_chunks), torch.cat(val_chunks), (n_cells, n_genes))
