@@ -72,7 +72,7 @@ class Direction:
         self.enc.train(); self.dec.train()
 
     def n_trained_params(self):
-        return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.requires_grad)
+        return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None)
 
 
 def _raw_decoder(S, out_dim, hidden, sample_factor):
@@ -174,7 +174,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    losses = (float(la), float(lb))
+    losses = (float(la.detach()), float(lb.detach()))
 
     # ---- roofline of the dominant kernel: fused AdamW, 28 B/param ---------------------------------
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in adam_ev)

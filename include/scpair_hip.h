@@ -69,7 +69,7 @@ int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, long ldx, con
 int scp_dec_chunks(int F);
 int scp_dec_kp(int K);
 long scp_dec_ws_floats(int B, int F, int K);
-long scp_dec_ws_doubles(int F);
+long scp_dec_ws_doubles(int B, int F);
 int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, long ldh, const float* W, long ldw,
                     const float* bias, const float* fs /* feature_scalar, nullable */,
                     const float* lrow /* lib or latent_lib logits, nullable */, int lrow_n /* 0, 1 or B */,

@@ -46,7 +46,7 @@ _SIGS = {
     "scp_dec_chunks": (I, [I]),
     "scp_dec_kp": (I, [I]),
     "scp_dec_ws_floats": (L, [I, I, I]),
-    "scp_dec_ws_doubles": (L, [I]),
+    "scp_dec_ws_doubles": (L, [I, I]),
     "scp_ber_dec_bce": (I, [I, I, I, I, P, L, P, L, P, P, P, I, P, P, P, P, P, P, P, L, P, P, P, L, P, P, P, I, P]),
     "scp_nb_dec_ll": (I, [I, I, I, I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, L, P, P, P, P, I, P]),
     "scp_mse_masked_fwd": (I, [P, L, P, L, I, I, P, P, P]),

@@ -64,8 +64,22 @@ __global__ void dec_finish_loss_kernel(const double* __restrict__ sum, double n_
 
 int scp_reduce_partials(const double* part, int n, int ncomp, double* out, hipStream_t stream);
 
+
 extern "C" int scp_dec_chunks(int F) { return (F + DEC_NPT * FT - 1) / (DEC_NPT * FT); }
 extern "C" int scp_dec_kp(int K) { return K <= 16 ? 16 : (K <= 48 ? 48 : 64); }
+
+// cell blocks per workgroup: enough (chunk x cell-group) workgroups to fill the chip a few times over
+static int dec_cpg(int B, int F) {
+  int nchunk = scp_dec_chunks(F), ncb = (B + CB - 1) / CB;
+  int ncg = (1024 + nchunk - 1) / nchunk;
+  if (ncg > ncb) ncg = ncb;
+  if (ncg < 1) ncg = 1;
+  return (ncb + ncg - 1) / ncg;
+}
+static int dec_ncg(int B, int F) {
+  int ncb = (B + CB - 1) / CB, cpg = dec_cpg(B, F);
+  return (ncb + cpg - 1) / cpg;
+}
 
 static int check_common(const char* who, int B, int F, int K, const float* h, const float* W, const float* bias,
                         const void* ws) {
@@ -74,14 +88,58 @@ static int check_common(const char* who, int B, int F, int K, const float* h, co
   return SCP_OK;
 }
 
-// Workspace layout (floats unless noted), nchunk = scp_dec_chunks(F), KP = scp_dec_kp(K):
-//   ws_d  : doubles  [nchunk + 8]
-//   ws_f  : floats   [nchunk*B*KP + nchunk*B*2]
+// Workspace layout, nchunk = scp_dec_chunks(F), KP = scp_dec_kp(K), ncg = cell groups:
+//   ws_d : doubles [nchunk*ncg + 8]
+//   ws_f : floats  [nchunk*B*KP] dh slabs | [nchunk*B*2] row slabs | [ncg*F*K] dW slabs | [3*ncg*F] db/dfs/dtheta slabs
 extern "C" long scp_dec_ws_floats(int B, int F, int K) {
-  long nchunk = scp_dec_chunks(F);
-  return nchunk * (long)B * scp_dec_kp(K) + nchunk * (long)B * 2;
+  long nchunk = scp_dec_chunks(F), ncg = dec_ncg(B, F);
+  return nchunk * (long)B * scp_dec_kp(K) + nchunk * (long)B * 2 + ncg * (long)F * K + 3 * ncg * (long)F;
 }
-extern "C" long scp_dec_ws_doubles(int F) { return scp_dec_chunks(F) + 8; }
+extern "C" long scp_dec_ws_doubles(int B, int F) { return (long)scp_dec_chunks(F) * dec_ncg(B, F) + 8; }
+
+struct DecPlan {
+  int nchunk, KP, cpg, ncg;
+  float *dh_slab, *row_slab, *dW_slab, *db_slab, *dfs_slab, *dth_slab;
+};
+
+static DecPlan make_plan(DecArgs& g, float* ws_f, float* dW, long lddw, float* db, float* dfs, float* dtheta) {
+  DecPlan p;
+  p.nchunk = scp_dec_chunks(g.F); p.KP = scp_dec_kp(g.K); p.cpg = dec_cpg(g.B, g.F); p.ncg = dec_ncg(g.B, g.F);
+  p.dh_slab = ws_f;
+  p.row_slab = ws_f ? p.dh_slab + (long)p.nchunk * g.B * p.KP : nullptr;
+  p.dW_slab = ws_f ? p.row_slab + (long)p.nchunk * g.B * 2 : nullptr;
+  p.db_slab = ws_f ? p.dW_slab + (long)p.ncg * g.F * g.K : nullptr;
+  p.dfs_slab = ws_f ? p.db_slab + (long)p.ncg * g.F : nullptr;
+  p.dth_slab = ws_f ? p.dfs_slab + (long)p.ncg * g.F : nullptr;
+  g.cpg = p.cpg;
+  g.dh_slab = p.dh_slab; g.row_slab = p.row_slab;
+  if (p.ncg == 1) {
+    g.dW = dW; g.lddw = lddw; g.cg_stride_w = 0; g.db = db; g.dfs = dfs; g.dtheta = dtheta;
+  } else {
+    g.dW = p.dW_slab; g.lddw = g.K; g.cg_stride_w = (long)g.F * g.K;
+    g.db = p.db_slab; g.dfs = dfs ? p.dfs_slab : nullptr; g.dtheta = dtheta ? p.dth_slab : nullptr;
+  }
+  return p;
+}
+
+// sum the per-cell-group slabs of the per-feature gradients (fixed order -> deterministic)
+static int finish_feature_grads(const DecPlan& p, const DecArgs& g, float* dW, long lddw, float* db, float* dfs,
+                                float* dtheta, hipStream_t stream) {
+  if (p.ncg == 1) return SCP_OK;
+  int rc = scp_slab_reduce(p.dW_slab, (long)g.F * g.K, p.ncg, g.F, g.K, g.K, nullptr, dW, lddw, stream);
+  if (rc) return rc;
+  rc = scp_slab_reduce(p.db_slab, g.F, p.ncg, 1, g.F, g.F, nullptr, db, g.F, stream);
+  if (rc) return rc;
+  if (dfs) {
+    rc = scp_slab_reduce(p.dfs_slab, g.F, p.ncg, 1, g.F, g.F, nullptr, dfs, g.F, stream);
+    if (rc) return rc;
+  }
+  if (dtheta) {
+    rc = scp_slab_reduce(p.dth_slab, g.F, p.ncg, 1, g.F, g.F, nullptr, dtheta, g.F, stream);
+    if (rc) return rc;
+  }
+  return SCP_OK;
+}
 
 extern "C" int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, long ldh, const float* W, long ldw,
                                const float* bias, const float* fs, const float* lrow, int lrow_n, const int32_t* t_ptr,
@@ -91,37 +149,39 @@ extern "C" int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, l
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_common("scp_ber_dec_bce", B, F, K, h, W, bias, ws_d);
   if (rc) return rc;
-  SCP_CHECK(t_ptr && t_key && loss, SCP_ERR_ARG, "scp_ber_dec_bce: null pointer");
-  SCP_CHECK(!train || (dW && db && dh && ws_f), SCP_ERR_ARG, "scp_ber_dec_bce: training needs dW, db, dh, ws_f");
+  SCP_CHECK(t_ptr && t_key && loss && ws_f, SCP_ERR_ARG, "scp_ber_dec_bce: null pointer");
+  SCP_CHECK(!train || (dW && db && dh), SCP_ERR_ARG, "scp_ber_dec_bce: training needs dW, db, dh");
   SCP_CHECK(lrow_n == 0 || lrow_n == 1 || lrow_n == B, SCP_ERR_ARG, "scp_ber_dec_bce: lrow_n must be 0, 1 or B");
-  int nchunk = scp_dec_chunks(F), KP = scp_dec_kp(K);
   DecArgs g = {};
   g.B = B; g.F = F; g.K = K; g.h = h; g.ldh = ldh; g.W = W; g.ldw = ldw; g.bias = bias; g.fs = fs;
   g.lrow = lrow; g.lrow_n = lrow_n; g.t_ptr = t_ptr; g.t_key = t_key; g.t_val = t_val; g.nnan = nnan; g.gout = gout;
-  g.loss_part = ws_d; g.dW = dW; g.lddw = lddw; g.db = db; g.dfs = dfs;
-  g.dh_slab = ws_f; g.row_slab = ws_f ? ws_f + (long)nchunk * B * KP : nullptr;
-  rc = train ? dec_dispatch<MODE_BER_TRAIN>(g, ns, nchunk, stream) : dec_dispatch<MODE_BER_EVAL>(g, ns, nchunk, stream);
+  g.loss_part = ws_d;
+  DecPlan p = make_plan(g, ws_f, dW, lddw, db, fs ? dfs : nullptr, nullptr);
+  int nblk = p.nchunk * p.ncg;
+  rc = train ? dec_dispatch<MODE_BER_TRAIN>(g, ns, p.nchunk, stream) : dec_dispatch<MODE_BER_EVAL>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  rc = scp_reduce_partials(ws_d, nchunk, 1, ws_d + nchunk, stream);
+  rc = scp_reduce_partials(ws_d, nblk, 1, ws_d + nblk, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_loss_kernel, dim3(1), dim3(1), 0, stream, ws_d + nchunk, (double)B * (double)F, nnan, loss);
+  hipLaunchKernelGGL(dec_finish_loss_kernel, dim3(1), dim3(1), 0, stream, ws_d + nblk, (double)B * (double)F, nnan, loss);
   SCP_LAUNCH_CHECK();
   if (train) {
-    hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, stream, g.dh_slab,
-                       nchunk, B, K, KP, dh, lddh);
+    rc = finish_feature_grads(p, g, dW, lddw, db, fs ? dfs : nullptr, nullptr, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, stream, p.dh_slab,
+                       p.nchunk, B, K, p.KP, dh, lddh);
     SCP_LAUNCH_CHECK();
     if (dlrow && lrow && lrow_n == B) {
-      hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, g.row_slab, nchunk, B, 0, 1.f,
-                         (const float*)nullptr, dlrow, (float*)nullptr);
+      hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, p.row_slab, p.nchunk, B, 0,
+                         1.f, (const float*)nullptr, dlrow, (float*)nullptr);
       SCP_LAUNCH_CHECK();
     }
   }
   return SCP_OK;
 }
 
-// NB decoder (zero_inflated=False path / likelihood 'nb'): loss = -mean log NB(y; L*softmax(a'), theta)
+// NB decoder (likelihood 'nb'): loss = -mean log NB(y; L*softmax(a'), theta)
 //   lrow = library size L per cell (sample_factor) or exp(leaky_relu(latent_lib)) precomputed by the caller
-//   lat  = latent_lib (only to form dlat = T * L'(lat) / ... ; null when lrow is data)
+//   lat  = latent_lib (only to form dlat = -(1/N) T lrelu'(lat)); null when lrow is data
 extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, long ldh, const float* W, long ldw,
                              const float* bias, const float* fs, const float* theta_param, const float* lrow,
                              const float* lat, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
@@ -133,41 +193,42 @@ extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, lon
   if (rc) return rc;
   SCP_CHECK(t_ptr && t_key && loss && lrow && rowbuf && ws_f, SCP_ERR_ARG, "scp_nb_dec_ll: null pointer");
   SCP_CHECK(!train || (dW && db && dh), SCP_ERR_ARG, "scp_nb_dec_ll: training needs dW, db, dh");
-  int nchunk = scp_dec_chunks(F), KP = scp_dec_kp(K);
   DecArgs g = {};
   g.B = B; g.F = F; g.K = K; g.h = h; g.ldh = ldh; g.W = W; g.ldw = ldw; g.bias = bias; g.fs = fs;
   g.theta_param = theta_param; g.lrow = lrow; g.lrow_n = B; g.t_ptr = t_ptr; g.t_key = t_key; g.t_val = t_val;
-  g.gout = gout; g.loss_part = ws_d; g.dW = dW; g.lddw = lddw; g.db = db; g.dfs = dfs; g.dtheta = dtheta;
-  g.dh_slab = ws_f; g.row_slab = ws_f + (long)nchunk * B * KP;
+  g.gout = gout; g.loss_part = ws_d;
+  DecPlan p = make_plan(g, ws_f, dW, lddw, db, fs ? dfs : nullptr, theta_param ? dtheta : nullptr);
+  int nblk = p.nchunk * p.ncg;
   float* lse = rowbuf;
   float* T = rowbuf + B;
   // pass 1: row log-sum-exp
-  rc = dec_dispatch<MODE_NB_STATS>(g, ns, nchunk, stream);
+  rc = dec_dispatch<MODE_NB_STATS>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, g.row_slab, nchunk, B, 1, 1.f,
+  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, p.row_slab, p.nchunk, B, 1, 1.f,
                      (const float*)nullptr, lse, (float*)nullptr);
   SCP_LAUNCH_CHECK();
   // pass 2: loss and T
   g.rowlse = lse;
-  rc = dec_dispatch<MODE_NB_LOSS>(g, ns, nchunk, stream);
+  rc = dec_dispatch<MODE_NB_LOSS>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  rc = scp_reduce_partials(ws_d, nchunk, 1, ws_d + nchunk, stream);
+  rc = scp_reduce_partials(ws_d, nblk, 1, ws_d + nblk, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_loss_kernel, dim3(1), dim3(1), 0, stream, ws_d + nchunk, (double)B * (double)F,
+  hipLaunchKernelGGL(dec_finish_loss_kernel, dim3(1), dim3(1), 0, stream, ws_d + nblk, (double)B * (double)F,
                      (const int32_t*)nullptr, loss);
   SCP_LAUNCH_CHECK();
   if (!train) return SCP_OK;
-  // dlat = d loss / d latent_lib = -(1/N) * T * lrelu'(lat)   (L = exp(lrelu(lat)) => dL/dlat = L*lrelu', dll/dL = T/L)
   float sc = -1.f / ((float)B * (float)F);
-  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, g.row_slab, nchunk, B,
+  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, p.row_slab, p.nchunk, B,
                      (dlat && lat) ? 2 : 0, sc, lat, T, dlat);
   SCP_LAUNCH_CHECK();
   // pass 3: gradients
   g.rowT = T;
-  rc = dec_dispatch<MODE_NB_GRAD>(g, ns, nchunk, stream);
+  rc = dec_dispatch<MODE_NB_GRAD>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, stream, g.dh_slab,
-                     nchunk, B, K, KP, dh, lddh);
+  rc = finish_feature_grads(p, g, dW, lddw, db, fs ? dfs : nullptr, theta_param ? dtheta : nullptr, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, stream, p.dh_slab,
+                     p.nchunk, B, K, p.KP, dh, lddh);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

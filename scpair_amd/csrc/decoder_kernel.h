@@ -51,7 +51,39 @@ struct DecArgs {
   float* dtheta;               // [F]
   float* dh_slab;              // [grid][B][KP]
   float* row_slab;             // [grid][B][2]   (Ber: dl ; NB stats: m,s ; NB loss: T)
+  // cell groups: blockIdx.y owns cell blocks [y*cpg, (y+1)*cpg); per-feature outputs of group y go to
+  // dW + y*cg_stride_w, db/dfs/dtheta + y*F (summed by the finishing kernels when ncg > 1)
+  int cpg;
+  long cg_stride_w;
 };
+
+// math flavour: accurate libm in the fp32-equivalent mode (NS=3), hardware exp/log/rcp in bf16 mode (NS=1)
+template <bool FAST> __device__ __forceinline__ float exp_(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FAST> __device__ __forceinline__ float log_(float x) { return FAST ? __logf(x) : logf(x); }
+template <bool FAST> __device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ float sigm_(float x) { return div_<FAST>(1.f, 1.f + exp_<FAST>(-x)); }
+
+// lgamma(y+th) - lgamma(th) - lgamma(y+1) and digamma(y+th) - digamma(th).  For small integer counts the exact
+// identities  sum_{i<y} log((th+i)/(i+1))  and  sum_{i<y} 1/(th+i)  avoid both the slow lgammaf/digamma
+// evaluations and the cancellation of lgamma(y+th)-lgamma(th) at large theta.
+template <bool FAST>
+__device__ __forceinline__ float lgam3(float y, float th) {
+  if (y <= 12.f && y == floorf(y)) {
+    float s = 0.f;
+    for (float i = 0.f; i < y; i += 1.f) s += log_<FAST>(div_<FAST>(th + i, i + 1.f));
+    return s;
+  }
+  return lgammaf(y + th) - lgammaf(th) - lgammaf(y + 1.f);
+}
+template <bool FAST>
+__device__ __forceinline__ float digam2(float y, float th) {
+  if (y <= 12.f && y == floorf(y)) {
+    float s = 0.f;
+    for (float i = 0.f; i < y; i += 1.f) s += div_<FAST>(1.f, th + i);
+    return s;
+  }
+  return digammaf_pos(y + th) - digammaf_pos(th);
+}
 
 template <int NS>
 __device__ __forceinline__ void img_put(__bf16* img, int rows, int ld, int row, int col, float v) {
@@ -68,6 +100,7 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
   constexpr bool NEED_LABELS = (MODE != MODE_NB_STATS);
   constexpr int LDK_ = KP + 8;
   constexpr int NTK = (KP + 31) / 32;      // 32-wide column tiles covering K
+  constexpr bool FAST = (NS == 1);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* hA = (__bf16*)smem_raw;                 // [NS][64][LDK_]   A of Z
   __bf16* WB = hA + NS * CB * LDK_;               // [NS][64][LDK_]   B of Z
@@ -86,6 +119,8 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
   const int ti = wave >> 1, tj = wave & 1;        // Z tile: cell half, feature half
   const int f_chunk0 = blockIdx.x * NPT * FT;
   const int ncb = (g.B + CB - 1) / CB;
+  const int cb_beg = blockIdx.y * g.cpg, cb_end = min(ncb, cb_beg + g.cpg);
+  const int bid = blockIdx.y * gridDim.x + blockIdx.x;
 
   float inv_n = 1.f;
   if (TRAIN) {
@@ -104,7 +139,7 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
   }
   double loss_acc = 0.0;
 
-  for (int cb = 0; cb < ncb; cb++) {
+  for (int cb = cb_beg; cb < cb_end; cb++) {
     const int c0 = cb * CB;
     // ---- stage the h block (both layouts) and the per-cell inputs -------------------------------
     for (int idx = tid; idx < CB * KP; idx += 256) {
@@ -118,7 +153,7 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
       bool ok = c < g.B;
       if (IS_BER) {
         float l = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 0.f;
-        rowv[tid] = g.lrow ? sigmoidf_(l) : 1.f;
+        rowv[tid] = g.lrow ? sigm_<FAST>(l) : 1.f;
       } else {
         rowv[tid] = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 1.f;          // L
         rowv[CB + tid] = (g.rowlse && ok) ? g.rowlse[c] : 0.f;                     // lse
@@ -185,10 +220,11 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
       const bool f_ok = f < g.F;
       const float bcol = f_ok ? g.bias[f] : 0.f;
       float fcol = 1.f;
-      if (g.fs && f_ok) fcol = sigmoidf_(g.fs[f]);
+      if (g.fs && f_ok) fcol = sigm_<FAST>(g.fs[f]);
       float thcol = 0.f;
-      if (!IS_BER && g.theta_param && f_ok) thcol = expf(g.theta_param[f]);
+      if (!IS_BER && g.theta_param && f_ok) thcol = exp_<FAST>(g.theta_param[f]);
       float dzv[16];
+      float lsum = 0.f;     // fp32 partial of this tile, folded into the fp64 accumulator once per tile
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int cl = ti * 32 + acc_row(e, lane);
@@ -196,18 +232,25 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
         dzv[e] = 0.f;
         if (IS_BER) {
           float zz = acc[e] + bcol;
-          float px = sigmoidf_(zz);
+          float px = sigm_<FAST>(zz);
           float sr = rowv[cl];
           float q = px * sr * fcol;
           float yv = ytile[cl * FT + fl];
           if (ok && yv == yv) {
-            float lq = fmaxf(logf(q), -100.f), l1q = fmaxf(logf(1.f - q), -100.f);
-            loss_acc -= (double)(yv * lq + (1.f - yv) * l1q);
+            float omq = 1.f - q;
+            if (yv == 0.f || yv == 1.f) {
+              // binary label: only one of the two BCE terms is non-zero
+              float arg = (yv == 0.f) ? omq : q;
+              lsum -= fmaxf(log_<FAST>(arg), -100.f);
+            } else {
+              lsum -= yv * fmaxf(log_<FAST>(q), -100.f) + (1.f - yv) * fmaxf(log_<FAST>(omq), -100.f);
+            }
             if (TRAIN) {
-              float dq = (q - yv) / fmaxf(q * (1.f - q), 1e-12f) * inv_n;
-              dzv[e] = dq * sr * fcol * px * (1.f - px);
-              racc0[e] += dq * px * fcol * sr * (1.f - sr);
-              dfs_acc[t] += dq * px * sr * fcol * (1.f - fcol);
+              float dq = div_<FAST>(q - yv, fmaxf(q * omq, 1e-12f)) * inv_n;
+              float t1 = dq * px;
+              dzv[e] = t1 * sr * fcol * (1.f - px);
+              racc0[e] += t1 * fcol * sr * (1.f - sr);
+              dfs_acc[t] += t1 * sr * fcol * (1.f - fcol);
               db_acc[t] += dzv[e];
             }
           }
@@ -219,28 +262,29 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
             if (ok) {
               float m_old = racc0[e];
               float m_new = fmaxf(m_old, ap);
-              racc1[e] = racc1[e] * expf(m_old - m_new) + expf(ap - m_new);
+              racc1[e] = racc1[e] * exp_<FAST>(m_old - m_new) + exp_<FAST>(ap - m_new);
               racc0[e] = m_new;
             }
           } else if (ok) {
             const float eps = 1e-8f;
             float L = rowv[cl], lse = rowv[CB + cl];
-            float scale = expf(ap - lse);
+            float scale = exp_<FAST>(ap - lse);
             float mu = L * scale;
-            float th = g.theta_param ? thcol : expf(a_);
+            float th = g.theta_param ? thcol : exp_<FAST>(a_);
             float s_ = th + mu + eps;
-            float lt = logf(th + eps), ls = logf(s_);
+            float lt = log_<FAST>(th + eps), ls = log_<FAST>(s_);
             float yv = ytile[cl * FT + fl];
-            float gmu = -th / s_;
-            if (yv > eps) gmu += yv * (1.f / (mu + eps) - 1.f / s_);
+            float rs = div_<FAST>(1.f, s_);
+            float gmu = -th * rs;
+            if (yv > eps) gmu += yv * (div_<FAST>(1.f, mu + eps) - rs);
             if (MODE == MODE_NB_LOSS) {
               float ll = th * (lt - ls);
-              if (yv > eps) ll += yv * (logf(mu + eps) - ls) + lgamma_terms(yv, th);
-              loss_acc -= (double)ll;
+              if (yv > eps) ll += yv * (log_<FAST>(mu + eps) - ls) + lgam3<FAST>(yv, th);
+              lsum -= ll;
               racc0[e] += gmu * mu;
             } else {   // MODE_NB_GRAD
-              float gth = lt - ls + th / (th + eps) - th / s_;
-              if (yv > eps) gth += -yv / s_ + digammaf_pos(yv + th) - digammaf_pos(th);
+              float gth = lt - ls + div_<FAST>(th, th + eps) - th * rs;
+              if (yv > eps) gth += -yv * rs + digam2<FAST>(yv, th);
               float T = rowv[2 * CB + cl];
               float dap = mu * gmu - scale * T;
               float da = dap * fcol;
@@ -256,12 +300,27 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
           }
         }
       }
+      loss_acc += (double)lsum;
       if (TRAIN) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int cl = ti * 32 + acc_row(e, lane);
           img_put<NS>(dzA, CB, LDZ, cl, fl, dzv[e]);
-          img_put<NS>(dzT, FT, LDZ, fl, cl, dzv[e]);
+        }
+        // dzT[feature][cell]: registers 4q..4q+3 are 4 consecutive cells -> one 8-byte store per term
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+          __bf16 tt[4][3];
+#pragma unroll
+          for (int j = 0; j < 4; j++) bf16_split<NS>(dzv[4 * q4 + j], tt[j]);
+          const int cl0 = ti * 32 + 8 * q4 + 4 * hq;
+#pragma unroll
+          for (int s2 = 0; s2 < NS; s2++) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = tt[j][s2];
+            *(bf16x4*)&dzT[(s2 * FT + fl) * LDZ + cl0] = o;
+          }
         }
         __syncthreads();
         // ---- dW tile += dZ^T h ; dh block += dZ W -----------------------------------------------
@@ -351,7 +410,7 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
   // ---- chunk-level outputs ------------------------------------------------------------------------
   if (MODE != MODE_NB_STATS && MODE != MODE_NB_GRAD) {
     double s = block_sum_d(loss_acc, dred);
-    if (tid == 0) g.loss_part[blockIdx.x] = s;
+    if (tid == 0) g.loss_part[bid] = s;
   }
   if (TRAIN) {
     const int mi = wave & 1, nj = wave >> 1;
@@ -365,7 +424,7 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
 #pragma unroll
           for (int e = 0; e < 16; e++) {
             int f = f0 + mi * 32 + acc_row(e, lane);
-            if (f < g.F) g.dW[(long)f * g.lddw + k] = accW[t][e];
+            if (f < g.F) g.dW[(long)blockIdx.y * g.cg_stride_w + (long)f * g.lddw + k] = accW[t][e];
           }
         }
       }
@@ -388,9 +447,10 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
         float v0 = cred[((0 * NPT + t) * 3 + 0) * FT + fl] + cred[((1 * NPT + t) * 3 + 0) * FT + fl];
         float v1 = cred[((0 * NPT + t) * 3 + 1) * FT + fl] + cred[((1 * NPT + t) * 3 + 1) * FT + fl];
         float v2 = cred[((0 * NPT + t) * 3 + 2) * FT + fl] + cred[((1 * NPT + t) * 3 + 2) * FT + fl];
-        if (g.db) g.db[f] = v0;
-        if (g.dfs) g.dfs[f] = v1;
-        if (g.dtheta) g.dtheta[f] = v2;
+        const long fo = (long)blockIdx.y * g.F + f;
+        if (g.db) g.db[fo] = v0;
+        if (g.dfs) g.dfs[fo] = v1;
+        if (g.dtheta) g.dtheta[fo] = v2;
       }
     }
   }
@@ -407,6 +467,8 @@ static size_t dec_smem() {
 
 template <int NS, int KP, int MODE>
 static int dec_launch(const DecArgs& g, int grid, hipStream_t stream) {
+  const int ncb_ = (g.B + CB - 1) / CB;
+  const int ncg_ = (ncb_ + g.cpg - 1) / g.cpg;
   static bool attr_done = false;
   size_t smem = dec_smem<NS, KP>();
   if (!attr_done) {
@@ -414,7 +476,7 @@ static int dec_launch(const DecArgs& g, int grid, hipStream_t stream) {
                                 (int)smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL((dec_kernel<NS, KP, DEC_NPT, MODE>), dim3(grid), dim3(256), smem, stream, g);
+  hipLaunchKernelGGL((dec_kernel<NS, KP, DEC_NPT, MODE>), dim3(grid, ncg_), dim3(256), smem, stream, g);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

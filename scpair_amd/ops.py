@@ -60,6 +60,29 @@ def gemm_nt(M, N, K, A, a_sr, a_sk, B, b_sr, b_sk, Cout, ldc, bias=None, accumul
                              ns or _ns(), _lib.stream()), "scp_gemm_nt")
 
 
+def slab_reduce(slabs, nslab, rows, cols, out, bias=None):
+    L = _lib.lib()
+    _lib.check(L.scp_slab_reduce(slabs.data_ptr(), rows * cols, nslab, rows, cols, cols, _lib.ptr(bias), out.data_ptr(),
+                                 cols, _lib.stream()), "scp_slab_reduce")
+
+
+def gemm_nt_auto(M, N, K, A, a_sr, a_sk, B, b_sr, b_sk, Cout, bias=None, ns=None):
+    """C[M,N] (contiguous) = A B^T + bias; few-tile / deep-K shapes (the 900->40 layers and their weight gradients)
+    are split along K into slabs so they do not run on a handful of workgroups, then reduced in a fixed order."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nsplit = 1
+    if tiles < 64 and K >= 512:
+        nsplit = max(1, min(K // 128, 256 // tiles, 32))
+    if nsplit > 1:
+        nsplit = _lib.lib().scp_gemm_split_count(K, nsplit)
+    if nsplit <= 1:
+        gemm_nt(M, N, K, A, a_sr, a_sk, B, b_sr, b_sk, Cout, N, bias=bias, ns=ns)
+        return
+    slabs = torch.empty((nsplit, M, N), dtype=torch.float32, device=Cout.device)
+    gemm_nt(M, N, K, A, a_sr, a_sk, B, b_sr, b_sk, slabs, N, nsplit=nsplit, ns=ns)
+    slab_reduce(slabs, nsplit, M, N, Cout, bias)
+
+
 def colsum(X, rows, cols, ld=None):
     L = _lib.lib()
     out = _empty((cols,), X)
@@ -89,7 +112,7 @@ class LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = Wc.shape[0]
         y = _empty((M, N), x)
-        gemm_nt(M, N, K, x, K, 1, Wc, K, 1, y, N, bias=_f32c(b))
+        gemm_nt_auto(M, N, K, x, K, 1, Wc, K, 1, y, bias=_f32c(b))
         ctx.save_for_backward(x, Wc)
         ctx.has_bias = b is not None
         return y
@@ -104,11 +127,11 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), x)
             # dx[m][j] = sum_n dy[m][n] W[n][j]
-            gemm_nt(M, K, N, dy, N, 1, W, 1, K, dx, K)
+            gemm_nt_auto(M, K, N, dy, N, 1, W, 1, K, dx)
         if ctx.needs_input_grad[1]:
             dW = _empty((N, K), x)
             # dW[n][j] = sum_m dy[m][n] x[m][j]
-            gemm_nt(N, K, M, dy, 1, N, x, 1, K, dW, K)
+            gemm_nt_auto(N, K, M, dy, 1, N, x, 1, K, dW)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N)
         return dx, dW, db
@@ -189,12 +212,15 @@ class FcnnLayerFn(torch.autograd.Function):
                 _lib.check(L.scp_spmm_dw(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), dY.data_ptr(), H,
                                          dW.data_ptr(), Ftot, ns, _lib.stream()), "scp_spmm_dw")
             else:
-                gemm_nt(H, F, Bn, dY, 1, H, xs, 1, F, dW, Ftot, ns=ns)
+                if C_ == 0:
+                    gemm_nt_auto(H, F, Bn, dY, 1, H, xs, 1, F, dW, ns=ns)
+                else:
+                    gemm_nt(H, F, Bn, dY, 1, H, xs, 1, F, dW, Ftot, ns=ns)
             if C_:
                 gemm_nt(H, C_, Bn, dY, 1, H, cov, 1, C_, dW, Ftot, ns=ns, c_off=F)
         if (not ctx.sparse) and ctx.needs_input_grad[0]:
             dx = torch.empty((Bn, F), dtype=torch.float32, device=dev)
-            gemm_nt(Bn, F, H, dY, H, 1, W, 1, Ftot, dx, F, ns=ns)
+            gemm_nt_auto(Bn, F, H, dY, H, 1, W, 1, Ftot, dx, ns=ns)
         return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None
 
 
@@ -208,7 +234,7 @@ def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
 def _dec_ws(B, F, K, dev):
     L = _lib.lib()
     ws_f = torch.empty(L.scp_dec_ws_floats(B, F, K), dtype=torch.float32, device=dev)
-    ws_d = torch.empty(L.scp_dec_ws_doubles(F), dtype=torch.float64, device=dev)
+    ws_d = torch.empty(L.scp_dec_ws_doubles(B, F), dtype=torch.float64, device=dev)
     return ws_f, ws_d
 
 
