@@ -42,6 +42,16 @@ int scp_spmm_dw(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t
                 const float* dY /* [ncells][ldy] */, long ldy, float* dW /* [N][ldw] */, long ldw, int ns,
                 void* stream);
 
+/* bf16 throughput path of the same layer (precision mode 'bf16'): the weight operand is a bf16 shadow copy
+ * [N][ldw] (ldw % 8 == 0, zero padded; kept current by scp_adamw_multi / scp_cast_bf16) and dY comes transposed
+ * as bf16 [N][ldt] (scp_transpose_bf16) */
+int scp_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
+int scp_transpose_bf16(const float* src, int rows, int cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
+int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
+                      const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream);
+int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
+                     const void* dYT, long ldt, float* dW, long ldw, void* stream);
+
 /* ---- dense layers: nn.Linear forward / dgrad / wgrad (utils.py:57; model.py:84, 92, 163, 217, 228,
  *      280, 331; pairedVAE.py:49-50, 111-119) as one strided GEMM  C[M,N] (+)= A[M,K] B[N,K]^T + bias ---- */
 int scp_gemm_nt(int M, int N, int K, const float* A, long a_row_stride, long a_k_stride, const float* B,
@@ -125,6 +135,8 @@ typedef struct {
   float* v;
   long n;
   float lr, weight_decay, bias_corr1, bias_corr2, grad_scale;
+  void* p_bf16;      /* optional bf16 shadow of p laid out [n / cols][ld_bf16], rewritten with the new weights */
+  long cols, ld_bf16;
 } ScpAdamTensor;
 int scp_adamw_multi(const ScpAdamTensor* tensors /* host array */, int n, float beta1, float beta2, float eps,
                     void* stream);

@@ -25,7 +25,8 @@ U64 = C.c_uint64
 
 class AdamTensor(C.Structure):
     _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", L),
-                ("lr", F), ("weight_decay", F), ("bias_corr1", F), ("bias_corr2", F), ("grad_scale", F)]
+                ("lr", F), ("weight_decay", F), ("bias_corr1", F), ("bias_corr2", F), ("grad_scale", F),
+                ("p_bf16", P), ("cols", L), ("ld_bf16", L)]
 
 
 _SIGS = {
@@ -37,6 +38,10 @@ _SIGS = {
     "scp_gemm_split_count": (I, [I, I]),
     "scp_spmm_fwd": (I, [I, I, I, P, P, P, P, L, P, L, P, I, I, P]),
     "scp_spmm_dw": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
+    "scp_cast_bf16": (I, [P, L, L, L, P, L, P]),
+    "scp_transpose_bf16": (I, [P, I, I, L, P, L, P]),
+    "scp_spmm_fwd_bf16": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
+    "scp_spmm_dw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
     "scp_gemm_nt": (I, [I, I, I, P, L, L, P, L, L, P, L, P, I, I, I, P]),
     "scp_slab_reduce": (I, [P, L, I, I, I, L, P, P, L, P]),
     "scp_colsum": (I, [P, L, I, I, P, P, P]),

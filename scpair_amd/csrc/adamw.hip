@@ -1,6 +1,7 @@
 // Fused multi-tensor AdamW (torch.optim.AdamW defaults as the reference uses them, model.py:698-701:
 // betas (0.9, 0.999), eps 1e-8, amsgrad False, decoupled decay p *= 1 - lr*wd).
-// HBM-bound: 16 B read (p, g, m, v) + 12 B written (p, m, v) per parameter = 28 B/param/step.
+// HBM-bound: 16 B read (p, g, m, v) + 12 B written (p, m, v) per parameter = 28 B/param/step
+// (+2 B/param for tensors that carry a bf16 shadow copy for the first-layer MFMA kernels).
 // Up to SCP_ADAM_MAX_TENSORS tensors per launch, descriptors passed by value (no host->device copy).
 #include "common.h"
 #include "scpair_hip.h"
@@ -44,6 +45,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
         pa[k] -= step_size * (ma[k] / denom);
       }
       *(float4*)(t.p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+      if (t.p_bf16) {
+        __bf16* sh = (__bf16*)t.p_bf16;
+        if ((t.cols & 3) == 0) {
+          long rr = i / t.cols, cc = i - rr * t.cols;
+          bf16x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; k++) o[k] = (__bf16)pa[k];
+          *(bf16x4*)(sh + rr * t.ld_bf16 + cc) = o;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            long rr = (i + k) / t.cols, cc = (i + k) - rr * t.cols;
+            sh[rr * t.ld_bf16 + cc] = (__bf16)pa[k];
+          }
+        }
+      }
       *(float4*)(t.m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
       *(float4*)(t.v + i) = make_float4(va[0], va[1], va[2], va[3]);
     } else {
@@ -54,7 +71,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
         m = m + (gk - m) * (1.f - b1);
         float v = t.v[i + k] * b2 + gk * gk * (1.f - b2);
         float denom = sqrtf(v) * inv_sqrt_bc2 + pk.eps;
-        t.p[i + k] = p - step_size * (m / denom);
+        p = p - step_size * (m / denom);
+        t.p[i + k] = p;
+        if (t.p_bf16) {
+          long rr = (i + k) / t.cols, cc = (i + k) - rr * t.cols;
+          ((__bf16*)t.p_bf16)[rr * t.ld_bf16 + cc] = (__bf16)p;
+        }
         t.m[i + k] = m;
         t.v[i + k] = v;
       }
@@ -75,6 +97,8 @@ extern "C" int scp_adamw_multi(const ScpAdamTensor* tensors, int n, float beta1,
       const ScpAdamTensor& t = tensors[i];
       SCP_CHECK(t.p && t.g && t.m && t.v, SCP_ERR_ARG, "scp_adamw_multi: null pointer in tensor %d", i);
       SCP_CHECK(t.n >= 0, SCP_ERR_ARG, "scp_adamw_multi: negative size in tensor %d", i);
+      SCP_CHECK(!t.p_bf16 || (t.cols > 0 && t.ld_bf16 >= t.cols && t.ld_bf16 % 8 == 0), SCP_ERR_ARG,
+                "scp_adamw_multi: bad bf16 shadow geometry in tensor %d", i);
       SCP_CHECK(t.bias_corr1 > 0.f && t.bias_corr2 > 0.f, SCP_ERR_ARG, "scp_adamw_multi: bias corrections must be > 0");
       if (t.n == 0) continue;
       pk.t[pk.n] = t;

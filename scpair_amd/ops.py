@@ -37,6 +37,34 @@ def next_seed() -> int:
     return ((torch.initial_seed() & 0xFFFFFFFF) << 24) + _cfg["seed_ctr"]
 
 
+# ---- bf16 shadow copies of first-layer weights (precision 'bf16') ------------------------------------------
+import weakref
+
+_shadows = weakref.WeakKeyDictionary()
+
+
+def shadow_of(W, create=True):
+    """bf16 copy [H, ld] (ld = cols rounded up to 8, zero padded) of a 2-D fp32 weight, for the bf16 first-layer
+    kernels.  It is refreshed here whenever torch has modified W (version counter) and rewritten by FusedAdamW
+    in the same kernel that updates W, so it never lags the master weights."""
+    ent = _shadows.get(W)
+    if ent is not None and ent[1] == W._version and ent[0].device == W.device:
+        return ent[0]
+    if not create:
+        return None
+    L = _lib.lib()
+    H, cols = W.shape
+    ld = (cols + 7) // 8 * 8
+    sh = ent[0] if (ent is not None and ent[0].shape == (H, ld) and ent[0].device == W.device) else \
+        torch.empty((H, ld), dtype=torch.bfloat16, device=W.device)
+    Wc = W.detach()
+    if not Wc.is_contiguous():
+        raise RuntimeError("first-layer weights must be contiguous")
+    _lib.check(L.scp_cast_bf16(Wc.data_ptr(), H, cols, cols, sh.data_ptr(), ld, _lib.stream()), "scp_cast_bf16")
+    _shadows[W] = (sh, W._version)
+    return sh
+
+
 def _f32c(t):
     if t is None:
         return None
@@ -147,8 +175,9 @@ def linear(x, W, b=None):
 # ------------------------------------------------------------------------------------------------
 class FcnnLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, cov, W, b, gamma, beta, slope, p_drop, seed, eps):
-        """x: dense [B, F] tensor or BatchTiles; cov: dense [B, C] or None; W: [H, F + C]."""
+    def forward(ctx, x, cov, W, b, gamma, beta, slope, p_drop, seed, eps, shadow=None):
+        """x: dense [B, F] tensor or BatchTiles; cov: dense [B, C] or None; W: [H, F + C];
+        shadow: bf16 copy of W for the bf16 sparse kernels (or None)."""
         L = _lib.lib()
         sparse = isinstance(x, BatchTiles)
         Wc = _f32c(W)
@@ -160,11 +189,21 @@ class FcnnLayerFn(torch.autograd.Function):
             raise ValueError(f"FCNN layer: weight expects {Ftot} inputs, got {F} (+{C_} covariates)")
         ns = _ns()
         dev = Wc.device
-        nsplit = _pick_split(Bn, H, F)
+        use_bf = sparse and ns == 1 and shadow is not None
+        if use_bf:
+            tiles_ = ((Bn + 255) // 256) * ((H + 127) // 128)
+            nsplit = max(1, min(768 // max(tiles_, 1), ((F + 63) // 64) // 4, 32))
+        else:
+            nsplit = _pick_split(Bn, H, F)
         nsplit = L.scp_gemm_split_count(F, nsplit)
         nslab = nsplit + (1 if C_ else 0)
         slabs = torch.empty((nslab, Bn, H), dtype=torch.float32, device=dev)
-        if sparse:
+        if use_bf:
+            _lib.check(L.scp_spmm_fwd_bf16(Bn, H, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val),
+                                           shadow.data_ptr(), shadow.shape[1], slabs.data_ptr(), H, nsplit,
+                                           _lib.stream()), "scp_spmm_fwd_bf16")
+            xs = None
+        elif sparse:
             _lib.check(L.scp_spmm_fwd(Bn, H, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), Wc.data_ptr(),
                                       Ftot, slabs.data_ptr(), H, None, nsplit, ns, _lib.stream()), "scp_spmm_fwd")
             xs = None
@@ -186,6 +225,7 @@ class FcnnLayerFn(torch.autograd.Function):
         ctx.tiles = x if sparse else None
         ctx.save_for_backward(xs, covc, Wc, g_, b_, xhat, rstd)
         ctx.cfg = (slope, p_drop, seed, Bn, H, F, C_, ns, b is not None)
+        ctx.use_bf = use_bf
         return out
 
     @staticmethod
@@ -207,7 +247,16 @@ class FcnnLayerFn(torch.autograd.Function):
         dx = dW = None
         if ctx.needs_input_grad[2]:
             dW = torch.empty((H, Ftot), dtype=torch.float32, device=dev)
-            if ctx.sparse:
+            if ctx.sparse and ctx.use_bf:
+                t = ctx.tiles
+                ldt = (Bn + 63) // 64 * 64
+                dYT = torch.empty((H, ldt), dtype=torch.bfloat16, device=dev)
+                _lib.check(L.scp_transpose_bf16(dY.data_ptr(), Bn, H, H, dYT.data_ptr(), ldt, _lib.stream()),
+                           "scp_transpose_bf16")
+                _lib.check(L.scp_spmm_dw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                                              dYT.data_ptr(), ldt, dW.data_ptr(), Ftot, _lib.stream()),
+                           "scp_spmm_dw_bf16")
+            elif ctx.sparse:
                 t = ctx.tiles
                 _lib.check(L.scp_spmm_dw(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), dY.data_ptr(), H,
                                          dW.data_ptr(), Ftot, ns, _lib.stream()), "scp_spmm_dw")
@@ -221,11 +270,14 @@ class FcnnLayerFn(torch.autograd.Function):
         if (not ctx.sparse) and ctx.needs_input_grad[0]:
             dx = torch.empty((Bn, F), dtype=torch.float32, device=dev)
             gemm_nt_auto(Bn, F, H, dY, H, 1, W, 1, Ftot, dx, ns=ns)
-        return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None
+        return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None, None
 
 
 def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
-    return FcnnLayerFn.apply(x, cov, W, b, gamma, beta, float(slope), float(p_drop), int(seed), float(eps))
+    shadow = None
+    if isinstance(x, BatchTiles) and _ns() == 1 and W.is_cuda and W.dtype == torch.float32 and W.is_contiguous():
+        shadow = shadow_of(W)
+    return FcnnLayerFn.apply(x, cov, W, b, gamma, beta, float(slope), float(p_drop), int(seed), float(eps), shadow)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -478,8 +530,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 t = st["step"]
+                sh = shadow_of(p, create=False) if p.ndim == 2 else None
                 d = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                    p.numel(), group["lr"], group["weight_decay"], 1 - b1 ** t, 1 - b2 ** t, grad_scale)
+                                    p.numel(), group["lr"], group["weight_decay"], 1 - b1 ** t, 1 - b2 ** t, grad_scale,
+                                    None if sh is None else sh.data_ptr(), p.shape[-1],
+                                    0 if sh is None else sh.shape[1])
                 by_hyper.setdefault((b1, b2, group["eps"]), []).append(d)
                 keep.append(g)
         for (b1, b2, eps), descs in by_hyper.items():

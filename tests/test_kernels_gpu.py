@@ -360,3 +360,28 @@ def test_error_reporting(S):
     assert rc == -1 and b"positive" in L.scp_last_error()
     with pytest.raises(RuntimeError):
         S.ops.linear(torch.randn(4, 4), torch.randn(4, 4), None)        # CPU tensors are refused, no fallback
+
+
+def test_bf16_shadow_tracks_weights(S):
+    """The bf16 shadow used by the bf16 first-layer kernels equals bf16(W) after FusedAdamW steps and after torch
+    modifies W in place (version counter)."""
+    S.ops.set_precision("bf16")
+    rng = np.random.default_rng(7)
+    B, F, H = 130, 333, 24                       # F not a multiple of 8: padded leading dimension
+    m = rand_csr(rng, B, F, 0.1)
+    tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(m, S.dev), np.arange(B))
+    W = torch.nn.Parameter((torch.randn(H, F) * 0.1).to(S.dev)); b = torch.nn.Parameter(torch.zeros(H, device=S.dev))
+    opt = S.ops.FusedAdamW([W, b], lr=1e-2, weight_decay=0.0)
+    for _ in range(3):
+        out = S.ops.fcnn_layer(tiles, None, W, b, None, None, 0.01)
+        opt.zero_grad(); out.square().mean().backward(); opt.step()
+        sh = S.ops.shadow_of(W, create=False)
+        assert sh is not None and sh.shape == (H, 336)
+        assert torch.equal(sh[:, :F], W.detach().bfloat16()) and bool((sh[:, F:] == 0).all())
+    with torch.no_grad():
+        W.mul_(0.5)
+    out = S.ops.fcnn_layer(tiles, None, W, b, None, None, 0.01)
+    assert torch.equal(S.ops.shadow_of(W, create=False)[:, :F], W.detach().bfloat16())
+    ref = torch.nn.functional.leaky_relu(tiles.to_dense().bfloat16().double() @ W.detach().bfloat16().double().t() + b.detach().double(), 0.01)
+    close(out, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    S.ops.set_precision("fp32")
