@@ -40,18 +40,25 @@ def next_seed() -> int:
 # ---- bf16 shadow copies of first-layer weights (precision 'bf16') ------------------------------------------
 import weakref
 
-_shadows = weakref.WeakKeyDictionary()
+_shadows = {}          # id(W) -> (weakref(W), shadow, version); tensors compare element-wise, so no WeakKeyDictionary
 
 
 def shadow_of(W, create=True):
     """bf16 copy [H, ld] (ld = cols rounded up to 8, zero padded) of a 2-D fp32 weight, for the bf16 first-layer
     kernels.  It is refreshed here whenever torch has modified W (version counter) and rewritten by FusedAdamW
     in the same kernel that updates W, so it never lags the master weights."""
-    ent = _shadows.get(W)
+    ent = _shadows.get(id(W))
+    if ent is not None and ent[0]() is not W:          # id reused by another tensor
+        ent = None
+    else:
+        ent = None if ent is None else (ent[1], ent[2])
     if ent is not None and ent[1] == W._version and ent[0].device == W.device:
         return ent[0]
     if not create:
         return None
+    if len(_shadows) > 64:
+        for k in [k for k, v in _shadows.items() if v[0]() is None]:
+            del _shadows[k]
     L = _lib.lib()
     H, cols = W.shape
     ld = (cols + 7) // 8 * 8
@@ -61,7 +68,7 @@ def shadow_of(W, create=True):
     if not Wc.is_contiguous():
         raise RuntimeError("first-layer weights must be contiguous")
     _lib.check(L.scp_cast_bf16(Wc.data_ptr(), H, cols, cols, sh.data_ptr(), ld, _lib.stream()), "scp_cast_bf16")
-    _shadows[W] = (sh, W._version)
+    _shadows[id(W)] = (weakref.ref(W), sh, W._version)
     return sh
 
 
