@@ -16,6 +16,7 @@
 
 #define LDK 72
 #define PF 4   // sparse entries prefetched per thread per K-step
+#define PCH 255 // K-steps whose entry offsets are staged in LDS at a time
 
 struct SpArgs {
   int ncells, N, F;          // cells, hidden width, features
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* As = (__bf16*)smem_raw;        // [256][LDK]
   __bf16* Bs = As + 256 * LDK;           // [128][LDK]
+  int* ptrs = (int*)(Bs + 128 * LDK);    // [4][PCH + 1] entry offsets of the next PCH K-steps, per cell block
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, hq = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
       int n = n0 + row, k = k0 + kc * 8;
       breg[i] = ld16(g.D + (long)n * g.ldd + k, n < g.N && k < g.ldd);
     }
-    p0 = p1 = 0;
-    if (cb_ok) {
-      p0 = g.ptr[pbase + k0];
-      p1 = g.ptr[pbase + kend];
+    {
+      int si = ((k0 - kbeg) >> 6) % PCH;
+      p0 = ptrs[cbl * (PCH + 1) + si];
+      p1 = ptrs[cbl * (PCH + 1) + si + 1];
     }
 #pragma unroll
     for (int i = 0; i < PF; i++) {
@@ -93,7 +95,21 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
     }
   };
 
-  if (kbeg < kend_all) prefetch(kbeg);
+  // entry offsets of K-steps [c0, c0 + PCH] of this slice -> LDS (one global latency per PCH steps instead of a
+  // dependent ptr -> key chain in every step)
+  auto load_ptrs = [&](int kfirst) {
+    for (int i = tid; i < 4 * (PCH + 1); i += 512) {
+      int c = i / (PCH + 1), sidx = i % (PCH + 1);
+      int cbx = (m0 >> 6) + c;
+      int k = min(kfirst + sidx * 64, kend_all);
+      ptrs[i] = (cbx < g.ncb) ? g.ptr[(long)cbx * g.F + k] : 0;
+    }
+  };
+  if (kbeg < kend_all) {
+    load_ptrs(kbeg);
+    __syncthreads();
+    prefetch(kbeg);
+  }
   for (int k0 = kbeg; k0 < kend_all; k0 += 64) {
     // zero A, write B
     {
@@ -119,7 +135,13 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
       As[(cbl * 64 + (key & 63)) * LDK + ((key >> 6) - k0)] = (__bf16)v;
     }
     __syncthreads();
-    if (k0 + 64 < kend_all) prefetch(k0 + 64);
+    if (k0 + 64 < kend_all) {
+      if ((((k0 + 64 - kbeg) >> 6) % PCH) == 0) {     // next step starts a new chunk of offsets (uniform)
+        load_ptrs(k0 + 64);
+        __syncthreads();
+      }
+      prefetch(k0 + 64);
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       bf16x8 af[2], bfr[2];
@@ -158,6 +180,7 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* As = (__bf16*)smem_raw;        // [128][LDK]   dYT tile  [hidden][cell]
   __bf16* Bs = As + 128 * LDK;           // [256][LDK]   X tile    [feature][cell]
+  int* ptrs = (int*)(Bs + 256 * LDK);    // [2][PCH + 1]: entry range [start, end) of this feature tile per cell block
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, hq = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
@@ -192,9 +215,8 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
       int m = m0 + row, k = k0 + kc * 8;
       areg[i] = ld16(g.D + (long)m * g.ldd + k, m < g.N && k < g.ldd);
     }
-    long pbase = (long)cb * g.F;
-    p0 = g.ptr[pbase + n0];
-    p1 = g.ptr[pbase + nend];
+    p0 = ptrs[cb % (PCH + 1)];
+    p1 = ptrs[(PCH + 1) + cb % (PCH + 1)];
 #pragma unroll
     for (int i = 0; i < PF; i++) {
       int e = p0 + tid + 512 * i;
@@ -203,6 +225,14 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
     }
   };
 
+  auto load_ptrs = [&](int cbfirst) {
+    for (int i = tid; i < 2 * (PCH + 1); i += 512) {
+      int which = i / (PCH + 1), cbx = cbfirst + i % (PCH + 1);
+      ptrs[i] = (cbx < g.ncb) ? g.ptr[(long)cbx * g.F + (which ? nend : n0)] : 0;
+    }
+  };
+  load_ptrs(0);
+  __syncthreads();
   prefetch(0);
   for (int cb = 0; cb < g.ncb; cb++) {
     {
@@ -227,7 +257,13 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
       Bs[((key >> 6) - n0) * LDK + (key & 63)] = (__bf16)v;
     }
     __syncthreads();
-    if (cb + 1 < g.ncb) prefetch(cb + 1);
+    if (cb + 1 < g.ncb) {
+      if (((cb + 1) % (PCH + 1)) == 0) {
+        load_ptrs(cb + 1);
+        __syncthreads();
+      }
+      prefetch(cb + 1);
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       bf16x8 af[2], bfr[2];
@@ -319,7 +355,7 @@ extern "C" int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr,
   SCP_CHECK(ldw % 8 == 0 && ldw >= F && ((uintptr_t)Wbf % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_fwd_bf16: shadow weights need a 16-byte aligned base and ld %% 8 == 0");
   static bool done = false;
-  size_t smem = (size_t)(256 + 128) * LDK * sizeof(__bf16);
+  size_t smem = (size_t)(256 + 128) * LDK * sizeof(__bf16) + 4 * (PCH + 1) * sizeof(int);
   int rc = set_smem((const void*)spmm_fwd_bf16_kernel, smem, &done);
   if (rc) return rc;
   SpArgs g = {};
@@ -346,7 +382,7 @@ extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, 
   SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_dw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
   static bool done = false;
-  size_t smem = (size_t)(256 + 128) * LDK * sizeof(__bf16);
+  size_t smem = (size_t)(256 + 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
   int rc = set_smem((const void*)spmm_dw_bf16_kernel, smem, &done);
   if (rc) return rc;
   SpArgs g = {};
