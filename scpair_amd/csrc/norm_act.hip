@@ -23,14 +23,19 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < MAXR; i++) {
     int c = lane + 64 * i;
-    float a = 0.f;
-    if (c < H) {
-      for (int sl = 0; sl < nslab; sl++) a += Y[(long)sl * slab_stride + (long)row * ldy + c];
-      if (bias) a += bias[c];
-    }
-    v[i] = a;
-    s += a;
+    v[i] = (bias && c < H) ? bias[c] : 0.f;
   }
+  // slab-major order: MAXR independent coalesced loads in flight per slab, slabs summed in a fixed order
+  for (int sl = 0; sl < nslab; sl++) {
+    const float* yr = Y + (long)sl * slab_stride + (long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) {
+      int c = lane + 64 * i;
+      if (c < H) v[i] += yr[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXR; i++) s += v[i];
   float rstd = 1.f, mean = 0.f;
   if (gamma) {
     mean = wave_sum(s) / (float)H;
