@@ -1,0 +1,73 @@
+"""World-size-2 gloo tests of the data-parallel gradient exchange (scpair_amd/distributed.py) on the CPU.
+The N-rank global-batch gradient must equal the single-process gradient of the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scpair_amd.distributed import GradSync
+    sync = GradSync(big=1000)
+    torch.manual_seed(0)
+    # a tiny model with one "big" (>= big elements) and several small tensors
+    W1 = torch.nn.Parameter(torch.randn(40, 50)); b1 = torch.nn.Parameter(torch.randn(40)); W2 = torch.nn.Parameter(torch.randn(3, 40))
+    params = [W1, b1, W2]
+    if rank != 0:
+        for p in params:
+            p.data.zero_()
+    sync.broadcast(params)                                    # everyone starts from rank 0's weights
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(10, 50, generator=g); Y = torch.randn(10, 3, generator=g)
+    rows = sync.shard(np.arange(10) if world == 2 else np.arange(10))   # ragged split when world does not divide 10
+    if world == 3:
+        assert [len(np.array_split(np.arange(10), 3)[r]) for r in range(3)] == [4, 3, 3]
+    x, y = X[rows], Y[rows]
+    loss = ((torch.relu(x @ W1.t() + b1) @ W2.t() - y) ** 2).mean()
+    loss.backward()
+    n_valid = float(y.numel())
+    sync.all_reduce_grads(params, n_valid)
+    gl = sync.weighted_mean(loss.detach(), n_valid)
+    num, den = sync.reduce_scalars(torch.tensor(float(rank + 1)), torch.tensor(2.0))
+    if rank == 0:
+        out.put(([p.grad.clone().numpy() for p in params], float(gl), float(num), float(den),
+                 [p.detach().clone().numpy() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_global_batch_gradient_equals_single_process(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    grads, gl, num, den, weights = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the full batch
+    torch.manual_seed(0)
+    W1 = torch.randn(40, 50, requires_grad=True); b1 = torch.randn(40, requires_grad=True); W2 = torch.randn(3, 40, requires_grad=True)
+    for w, got in zip((W1, b1, W2), weights):
+        np.testing.assert_array_equal(w.detach().numpy(), got)
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(10, 50, generator=g); Y = torch.randn(10, 3, generator=g)
+    loss = ((torch.relu(X @ W1.t() + b1) @ W2.t() - Y) ** 2).mean()
+    loss.backward()
+    for ref, got in zip((W1, b1, W2), grads):
+        np.testing.assert_allclose(got, ref.grad.numpy(), rtol=1e-4, atol=1e-5)
+    assert abs(gl - float(loss)) < 1e-5 * abs(float(loss))
+    assert num == sum(range(1, world + 1)) and den == 2.0 * world
