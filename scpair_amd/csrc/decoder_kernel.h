@@ -139,27 +139,59 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
   }
   double loss_acc = 0.0;
 
+  // ---- software pipeline state: operands of the UPCOMING iteration live in registers -------------------
+  constexpr int WPT = FT * KP / 256;            // elements per thread of a 64 x KP operand block
+  constexpr int EPF = 2;                        // label entries prefetched per thread
+  float wreg[WPT], hreg[WPT];
+  int ekey[EPF];
+  float evl[EPF];
+  int ep0 = 0, ep1 = 0;                         // entry range of the upcoming iteration
+  int pn0 = 0, pn1 = 0;                         // entry range of the iteration after it (ptr loaded one step earlier)
+  auto load_w = [&](int f0n) {
+#pragma unroll
+    for (int j = 0; j < WPT; j++) {
+      int idx = tid + 256 * j;
+      int p = idx / KP, k = idx % KP;
+      wreg[j] = (f0n + p < g.F && k < g.K) ? g.W[(long)(f0n + p) * g.ldw + k] : 0.f;
+    }
+  };
+  auto load_h = [&](int c0n) {
+#pragma unroll
+    for (int j = 0; j < WPT; j++) {
+      int idx = tid + 256 * j;
+      int c = idx / KP, k = idx % KP;
+      hreg[j] = (c0n + c < g.B && k < g.K) ? g.h[(long)(c0n + c) * g.ldh + k] : 0.f;
+    }
+  };
+  auto load_ptr = [&](int cbx, int f0x) {
+    long base = (long)cbx * g.F;
+    pn0 = g.t_ptr[base + f0x];
+    pn1 = g.t_ptr[base + min(f0x + FT, g.F)];
+  };
+  auto load_entries = [&]() {
+    ep0 = pn0; ep1 = pn1;
+#pragma unroll
+    for (int i = 0; i < EPF; i++) {
+      int e = ep0 + tid + 256 * i;
+      ekey[i] = (e < ep1) ? g.t_key[e] : -1;
+      evl[i] = (e < ep1 && g.t_val) ? g.t_val[e] : 1.f;
+    }
+  };
+  const int ntl = min(NPT, (g.F - f_chunk0 + FT - 1) / FT);     // valid feature tiles of this chunk (>= 1)
+  if (cb_beg < cb_end) {
+    load_h(cb_beg * CB);
+    load_w(f_chunk0);
+    if (NEED_LABELS) {
+      load_ptr(cb_beg, f_chunk0);
+      load_entries();
+      // range of the second iteration
+      if (ntl > 1) load_ptr(cb_beg, f_chunk0 + FT);
+      else if (cb_beg + 1 < cb_end) load_ptr(cb_beg + 1, f_chunk0);
+    }
+  }
+
   for (int cb = cb_beg; cb < cb_end; cb++) {
     const int c0 = cb * CB;
-    // ---- stage the h block (both layouts) and the per-cell inputs -------------------------------
-    for (int idx = tid; idx < CB * KP; idx += 256) {
-      int c = idx / KP, k = idx % KP;
-      float v = (c0 + c < g.B && k < g.K) ? g.h[(long)(c0 + c) * g.ldh + k] : 0.f;
-      img_put<NS>(hA, CB, LDK_, c, k, v);
-      if (TRAIN) img_put<NS>(hT, KP, LDZ, k, c, v);
-    }
-    if (tid < CB) {
-      int c = c0 + tid;
-      bool ok = c < g.B;
-      if (IS_BER) {
-        float l = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 0.f;
-        rowv[tid] = g.lrow ? sigm_<FAST>(l) : 1.f;
-      } else {
-        rowv[tid] = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 1.f;          // L
-        rowv[CB + tid] = (g.rowlse && ok) ? g.rowlse[c] : 0.f;                     // lse
-        rowv[2 * CB + tid] = (g.rowT && ok) ? g.rowT[c] : 0.f;                     // T
-      }
-    }
     f32x16 accH;
 #pragma unroll
     for (int e = 0; e < 16; e++) accH[e] = 0.f;
@@ -173,26 +205,67 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
 #pragma unroll
     for (int t = 0; t < NPT; t++) {
       const int f0 = f_chunk0 + t * FT;
-      if (f0 >= g.F) break;                       // uniform
+      if (t >= ntl) break;                        // uniform
       __syncthreads();                            // previous iteration's readers are done
-      // ---- stage W tile (both layouts), clear label tile ----------------------------------------
-      for (int idx = tid; idx < FT * KP; idx += 256) {
+      if (t == 0) {
+        // ---- h block (both layouts) and the per-cell inputs, from the prefetch registers ---------------
+#pragma unroll
+        for (int j = 0; j < WPT; j++) {
+          int idx = tid + 256 * j;
+          int c = idx / KP, k = idx % KP;
+          img_put<NS>(hA, CB, LDK_, c, k, hreg[j]);
+          if (TRAIN) img_put<NS>(hT, KP, LDZ, k, c, hreg[j]);
+        }
+        if (tid < CB) {
+          int c = c0 + tid;
+          bool ok = c < g.B;
+          if (IS_BER) {
+            float l = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 0.f;
+            rowv[tid] = g.lrow ? sigm_<FAST>(l) : 1.f;
+          } else {
+            rowv[tid] = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 1.f;          // L
+            rowv[CB + tid] = (g.rowlse && ok) ? g.rowlse[c] : 0.f;                     // lse
+            rowv[2 * CB + tid] = (g.rowT && ok) ? g.rowT[c] : 0.f;                     // T
+          }
+        }
+      }
+      // ---- W tile (both layouts) from the prefetch registers, clear label tile ---------------------
+#pragma unroll
+      for (int j = 0; j < WPT; j++) {
+        int idx = tid + 256 * j;
         int p = idx / KP, k = idx % KP;
-        float v = (f0 + p < g.F && k < g.K) ? g.W[(long)(f0 + p) * g.ldw + k] : 0.f;
-        img_put<NS>(WB, FT, LDK_, p, k, v);
-        if (TRAIN) img_put<NS>(WT, KP, LDZ, k, p, v);
+        img_put<NS>(WB, FT, LDK_, p, k, wreg[j]);
+        if (TRAIN) img_put<NS>(WT, KP, LDZ, k, p, wreg[j]);
       }
       if (NEED_LABELS) {
         float4 z4 = {0.f, 0.f, 0.f, 0.f};
         for (int idx = tid; idx < CB * FT / 4; idx += 256) ((float4*)ytile)[idx] = z4;
         __syncthreads();
-        long base = (long)cb * g.F;
-        int fend = min(f0 + FT, g.F);
-        int p0 = g.t_ptr[base + f0], p1 = g.t_ptr[base + fend];
-        for (int e = p0 + tid; e < p1; e += 256) {
+#pragma unroll
+        for (int i = 0; i < EPF; i++)
+          if (ekey[i] >= 0) ytile[(ekey[i] & 63) * FT + ((ekey[i] >> 6) - f0)] = evl[i];
+        for (int e = ep0 + tid + 256 * EPF; e < ep1; e += 256) {
           int key = g.t_key[e];
           float v = g.t_val ? g.t_val[e] : 1.f;
           ytile[(key & 63) * FT + ((key >> 6) - f0)] = v;
+        }
+      }
+      // ---- issue the loads of the NEXT iteration; they complete under the MFMA + epilogue below -------
+      {
+        const bool more_t = (t + 1 < ntl);
+        const int cbn = more_t ? cb : cb + 1;
+        const int f0n = more_t ? f0 + FT : f_chunk0;
+        if (cbn < cb_end) {
+          load_w(f0n);
+          if (!more_t) load_h(cbn * CB);
+          if (NEED_LABELS) {
+            load_entries();                       // uses the range fetched one iteration ago
+            // range of the iteration after the next one
+            const bool more_t2 = more_t ? (t + 2 < ntl) : (1 < ntl);
+            const int cb2 = more_t2 ? cbn : cbn + 1;
+            const int f02 = more_t2 ? f0n + FT : f_chunk0;
+            if (cb2 < cb_end) load_ptr(cb2, f02);
+          }
         }
       }
       __syncthreads();
