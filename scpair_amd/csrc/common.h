@@ -117,6 +117,22 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
   return r;
 }
 
+// p[r * stride] summed over r = y, y+16, y+32, ... < n, four loads in flight, fixed order
+__device__ __forceinline__ float strided_sum16(const float* __restrict__ p, long stride, int n, int y) {
+  float s = 0.f;
+  int r = y;
+  for (; r + 48 < n; r += 64) {
+    float a0 = p[(long)r * stride], a1 = p[(long)(r + 16) * stride], a2 = p[(long)(r + 32) * stride],
+          a3 = p[(long)(r + 48) * stride];
+    s += a0;
+    s += a1;
+    s += a2;
+    s += a3;
+  }
+  for (; r < n; r += 16) s += p[(long)r * stride];
+  return s;
+}
+
 // ---- special functions -----------------------------------------------------------------------
 // softplus with torch's threshold (F.softplus default beta=1, threshold=20)
 __device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }

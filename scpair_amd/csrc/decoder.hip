@@ -19,40 +19,79 @@ static int dec_dispatch(const DecArgs& g, int ns, int grid, hipStream_t stream) 
 }
 
 // ---- finishing kernels ------------------------------------------------------------------------------
+// Workgroup = 64 outputs x 16 chunk groups (dim3(64,16)): group y folds chunks y, y+16, ...; the 16 group
+// results are then combined in ascending order, so every output is a fixed-order (deterministic) reduction.
 // dh[b][k] = sum_chunk slab[chunk][b][k]
-__global__ __launch_bounds__(256) void dec_finish_dh_kernel(const float* __restrict__ slab, int nchunk, int B, int K, int KP,
-                                                            float* __restrict__ dh, long lddh) {
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)B * K) return;
-  int b = (int)(i / K), k = (int)(i % K);
-  float s = 0.f;
-  for (int c = 0; c < nchunk; c++) s += slab[((long)c * B + b) * KP + k];
-  dh[(long)b * lddh + k] = s;
+__global__ __launch_bounds__(1024) void dec_finish_dh_kernel(const float* __restrict__ slab, int nchunk, int B, int K,
+                                                             int KP, float* __restrict__ dh, long lddh) {
+  __shared__ float red[16][64];
+  int x = threadIdx.x, y = threadIdx.y;
+  long j = (long)blockIdx.x * 64 + x;   // b * KP + k
+  bool ok = j < (long)B * KP;
+  float s = ok ? strided_sum16(slab + j, (long)B * KP, nchunk, y) : 0.f;
+  red[y][x] = s;
+  __syncthreads();
+  if (y == 0 && ok) {
+    int b = (int)(j / KP), k = (int)(j % KP);
+    if (k < K) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; q++) t += red[q][x];
+      dh[(long)b * lddh + k] = t;
+    }
+  }
 }
 
 // row_mode 0: out0[b] = sum_chunk slab[.][b][0]                    (Ber dl / NB T)
 // row_mode 1: (m,s) merge -> out0[b] = m + log s                    (NB log-sum-exp)
 // row_mode 2: like 0, and out1[b] = out0[b] * dscale(lat[b])        (NB dlatent_lib = T * lrelu'(lat))
-__global__ __launch_bounds__(256) void dec_finish_rows_kernel(const float* __restrict__ slab, int nchunk, int B,
-                                                              int row_mode, float scale_, const float* __restrict__ aux,
-                                                              float* __restrict__ out0, float* __restrict__ out1) {
-  int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= B) return;
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+  float mn = fmaxf(m, m2);
+  float e1 = (m == -INFINITY) ? 0.f : expf(m - mn), e2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+  s = s * e1 + s2 * e2;
+  m = mn;
+}
+__global__ __launch_bounds__(1024) void dec_finish_rows_kernel(const float* __restrict__ slab, int nchunk, int B,
+                                                               int row_mode, float scale_, const float* __restrict__ aux,
+                                                               float* __restrict__ out0, float* __restrict__ out1) {
+  __shared__ float red[2][16][64];
+  int x = threadIdx.x, y = threadIdx.y;
+  int b = blockIdx.x * 64 + x;
+  bool ok = b < B;
   if (row_mode == 1) {
     float m = -INFINITY, s = 0.f;
-    for (int c = 0; c < nchunk; c++) {
-      float m2 = slab[((long)c * B + b) * 2], s2 = slab[((long)c * B + b) * 2 + 1];
-      float mn = fmaxf(m, m2);
-      float e1 = (m == -INFINITY) ? 0.f : expf(m - mn), e2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
-      s = s * e1 + s2 * e2;
-      m = mn;
+    if (ok) {
+      int c = y;
+      for (; c + 16 < nchunk; c += 32) {
+        float2 p0 = *(const float2*)&slab[((long)c * B + b) * 2];
+        float2 p1 = *(const float2*)&slab[((long)(c + 16) * B + b) * 2];
+        lse_merge(m, s, p0.x, p0.y);
+        lse_merge(m, s, p1.x, p1.y);
+      }
+      for (; c < nchunk; c += 16) {
+        float2 p0 = *(const float2*)&slab[((long)c * B + b) * 2];
+        lse_merge(m, s, p0.x, p0.y);
+      }
     }
-    out0[b] = m + logf(s);
+    red[0][y][x] = m;
+    red[1][y][x] = s;
+    __syncthreads();
+    if (y == 0 && ok) {
+      float mm = -INFINITY, ss = 0.f;
+      for (int q = 0; q < 16; q++) lse_merge(mm, ss, red[0][q][x], red[1][q][x]);
+      out0[b] = mm + logf(ss);
+    }
   } else {
-    float s = 0.f;
-    for (int c = 0; c < nchunk; c++) s += slab[((long)c * B + b) * 2];
-    out0[b] = s;
-    if (row_mode == 2 && out1) out1[b] = s * scale_ * ((aux[b] > 0.f) ? 1.f : 0.01f);
+    float s = ok ? strided_sum16(slab + (long)b * 2, (long)B * 2, nchunk, y) : 0.f;
+    red[0][y][x] = s;
+    __syncthreads();
+    if (y == 0 && ok) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; q++) t += red[0][q][x];
+      out0[b] = t;
+      if (row_mode == 2 && out1) out1[b] = t * scale_ * ((aux[b] > 0.f) ? 1.f : 0.01f);
+    }
   }
 }
 
@@ -167,11 +206,11 @@ extern "C" int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, l
   if (train) {
     rc = finish_feature_grads(p, g, dW, lddw, db, fs ? dfs : nullptr, nullptr, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, stream, p.dh_slab,
+    hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * p.KP + 63) / 64)), dim3(64, 16), 0, stream, p.dh_slab,
                        p.nchunk, B, K, p.KP, dh, lddh);
     SCP_LAUNCH_CHECK();
     if (dlrow && lrow && lrow_n == B) {
-      hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, p.row_slab, p.nchunk, B, 0,
+      hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 63) / 64), dim3(64, 16), 0, stream, p.row_slab, p.nchunk, B, 0,
                          1.f, (const float*)nullptr, dlrow, (float*)nullptr);
       SCP_LAUNCH_CHECK();
     }
@@ -204,7 +243,7 @@ extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, lon
   // pass 1: row log-sum-exp
   rc = dec_dispatch<MODE_NB_STATS>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, p.row_slab, p.nchunk, B, 1, 1.f,
+  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 63) / 64), dim3(64, 16), 0, stream, p.row_slab, p.nchunk, B, 1, 1.f,
                      (const float*)nullptr, lse, (float*)nullptr);
   SCP_LAUNCH_CHECK();
   // pass 2: loss and T
@@ -218,7 +257,7 @@ extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, lon
   SCP_LAUNCH_CHECK();
   if (!train) return SCP_OK;
   float sc = -1.f / ((float)B * (float)F);
-  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, p.row_slab, p.nchunk, B,
+  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 63) / 64), dim3(64, 16), 0, stream, p.row_slab, p.nchunk, B,
                      (dlat && lat) ? 2 : 0, sc, lat, T, dlat);
   SCP_LAUNCH_CHECK();
   // pass 3: gradients
@@ -227,7 +266,7 @@ extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, lon
   if (rc) return rc;
   rc = finish_feature_grads(p, g, dW, lddw, db, fs ? dfs : nullptr, theta_param ? dtheta : nullptr, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, stream, p.dh_slab,
+  hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * p.KP + 63) / 64)), dim3(64, 16), 0, stream, p.dh_slab,
                      p.nchunk, B, K, p.KP, dh, lddh);
   SCP_LAUNCH_CHECK();
   return SCP_OK;

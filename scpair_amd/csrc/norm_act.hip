@@ -2,8 +2,9 @@
 // LeakyReLU/ReLU -> Dropout, forward and backward.  (BatchNorm1d, which the reference places AFTER
 // the activation, is a separate column-statistics kernel: bn_fwd / bn_bwd below.)
 //
-// One wave per row; a row (H <= 64*MAXR columns) lives in registers, so the forward reads the slabs
-// once and writes xhat + out once, the backward reads dOut + xhat once and writes dY once.
+// A row lives in registers, so the forward reads the slabs once and writes xhat + out once, the backward
+// reads dOut + xhat once and writes dY once.  Narrow rows (H <= 64) use one wave per row; wider rows use
+// one 256-thread workgroup per row (16 waves per CU at batch 1024, several slab loads in flight per lane).
 #include "common.h"
 #include "scpair_hip.h"
 
@@ -140,20 +141,197 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
   }
 }
 
-// out[w][c] = sum_blk partials[blk][w][c]   (fixed order -> deterministic)
-__global__ void colsum_reduce_kernel(const float* __restrict__ partials, int nblk, int nw, int H,
-                                     float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nw * H) return;
-  int w = idx / H, c = idx % H;
-  float* o = w == 0 ? o0 : (w == 1 ? o1 : o2);
-  if (!o) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; b++) s += partials[((long)b * nw + w) * H + c];
-  o[c] = s;
+
+// sum over the 256 threads of a workgroup, result in every thread (red: 4 floats per value)
+__device__ __forceinline__ void block_allsum2(float& a, float& b, float (*red)[4]) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[0][w] = a;
+    red[1][w] = b;
+  }
+  __syncthreads();
+  a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
 }
 
-extern "C" int scp_ln_act_bwd_grid(int B) {
+// forward, one workgroup per row, H <= 256*CPT
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_act_fwd_row_kernel(const float* __restrict__ Y, long ldy, long slab_stride,
+                                                             int nslab, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int B, int H, float eps,
+                                                             float slope, float p_drop, uint64_t seed,
+                                                             float* __restrict__ xhat, long ldx,
+                                                             float* __restrict__ rstd_out, float* __restrict__ out,
+                                                             long ldo) {
+  __shared__ float red[2][4];
+  int row = blockIdx.x, tid = threadIdx.x;
+  float v[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; i++) {
+    int c = tid + 256 * i;
+    v[i] = (bias && c < H) ? bias[c] : 0.f;
+  }
+  const float* yr = Y + (long)row * ldy;
+  int sl = 0;
+  // four slabs of loads in flight; slabs are still added in ascending order
+  for (; sl + 4 <= nslab; sl += 4) {
+    float t[4][CPT];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int i = 0; i < CPT; i++) {
+        int c = tid + 256 * i;
+        t[j][i] = (c < H) ? yr[(long)(sl + j) * slab_stride + c] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int i = 0; i < CPT; i++) v[i] += t[j][i];
+  }
+  for (; sl < nslab; sl++)
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+      int c = tid + 256 * i;
+      if (c < H) v[i] += yr[(long)sl * slab_stride + c];
+    }
+  float rstd = 1.f, mean = 0.f;
+  if (gamma) {
+    float s = 0.f, dummy = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) s += v[i];
+    block_allsum2(s, dummy, red);
+    mean = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+      int c = tid + 256 * i;
+      float d = (c < H) ? v[i] - mean : 0.f;
+      q += d * d;
+    }
+    block_allsum2(q, dummy, red);
+    rstd = 1.f / sqrtf(q / (float)H + eps);
+    if (tid == 0 && rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < CPT; i++) {
+    int c = tid + 256 * i;
+    if (c < H) {
+      float xh = gamma ? (v[i] - mean) * rstd : v[i];
+      float z = gamma ? xh * gamma[c] + beta[c] : xh;
+      float a = z > 0.f ? z : z * slope;
+      a *= keep_scale(seed, (uint64_t)row * H + c, p_drop);
+      if (xhat) xhat[(long)row * ldx + c] = xh;
+      out[(long)row * ldo + c] = a;
+    }
+  }
+}
+
+// backward, one workgroup per row (rows strided over the grid); every thread owns CPT columns, so the
+// column partials of dgamma / dbeta / dbias need no cross-wave step
+template <int CPT>
+__global__ __launch_bounds__(256) void ln_act_bwd_row_kernel(const float* __restrict__ dOut, long ldo,
+                                                             const float* __restrict__ xhat, long ldx,
+                                                             const float* __restrict__ rstd_in,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int B, int H,
+                                                             float slope, float p_drop, uint64_t seed,
+                                                             float* __restrict__ dY, long ldy,
+                                                             float* __restrict__ partials /* [grid][3][H] */) {
+  __shared__ float red[2][4];
+  int tid = threadIdx.x;
+  float ag[CPT], ab[CPT], ad[CPT], gam[CPT], bet[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; i++) {
+    int c = tid + 256 * i;
+    ag[i] = ab[i] = ad[i] = 0.f;
+    gam[i] = (gamma && c < H) ? gamma[c] : 1.f;
+    bet[i] = (gamma && c < H) ? beta[c] : 0.f;
+  }
+  for (int row = blockIdx.x; row < B; row += gridDim.x) {
+    float dxh[CPT], xh[CPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+      int c = tid + 256 * i;
+      dxh[i] = 0.f;
+      xh[i] = 0.f;
+      if (c < H) {
+        float x = xhat[(long)row * ldx + c];
+        float g = dOut[(long)row * ldo + c] * keep_scale(seed, (uint64_t)row * H + c, p_drop);
+        float z = gamma ? x * gam[i] + bet[i] : x;
+        float dz = z > 0.f ? g : g * slope;
+        xh[i] = x;
+        if (gamma) {
+          ag[i] += dz * x;
+          ab[i] += dz;
+          dxh[i] = dz * gam[i];
+          s1 += dxh[i];
+          s2 += dxh[i] * x;
+        } else {
+          dxh[i] = dz;
+        }
+      }
+    }
+    float rstd = 1.f;
+    if (gamma) {
+      block_allsum2(s1, s2, red);
+      s1 /= (float)H;
+      s2 /= (float)H;
+      rstd = rstd_in[row];
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+      int c = tid + 256 * i;
+      if (c < H) {
+        float d = gamma ? rstd * (dxh[i] - s1 - xh[i] * s2) : dxh[i];
+        dY[(long)row * ldy + c] = d;
+        ad[i] += d;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CPT; i++) {
+    int c = tid + 256 * i;
+    if (c < H) {
+      partials[((long)blockIdx.x * 3 + 0) * H + c] = ag[i];
+      partials[((long)blockIdx.x * 3 + 1) * H + c] = ab[i];
+      partials[((long)blockIdx.x * 3 + 2) * H + c] = ad[i];
+    }
+  }
+}
+
+// out[w][c] = sum_blk partials[blk][w][c]   (fixed order -> deterministic)
+// workgroup = 64 columns x 16 row groups; group y sums blocks y, y+16, ...; the 16 group sums are added in order
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ partials, int nblk, int nw, int H,
+                                                             float* __restrict__ o0, float* __restrict__ o1,
+                                                             float* __restrict__ o2) {
+  __shared__ float red[16][64];
+  int x = threadIdx.x, y = threadIdx.y;
+  int idx = blockIdx.x * 64 + x;
+  bool ok = idx < nw * H;
+  float s = 0.f;
+  if (ok) s = strided_sum16(partials + idx, (long)nw * H, nblk, y);
+  red[y][x] = s;
+  __syncthreads();
+  if (y == 0 && ok) {
+    int w = idx / H, c = idx % H;
+    float* o = w == 0 ? o0 : (w == 1 ? o1 : o2);
+    if (o) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) t += red[k][x];
+      o[c] = t;
+    }
+  }
+}
+
+// upper bound of the backward grid (sizes the caller's partials workspace: [grid][3][H])
+extern "C" int scp_ln_act_bwd_grid(int B) { return B > 256 ? 256 : (B < 1 ? 1 : B); }
+static int ln_bwd_wave_grid(int B) {
   int g = (B + 3) / 4;
   return g > 128 ? 128 : (g < 1 ? 1 : g);
 }
@@ -172,11 +350,15 @@ extern "C" int scp_ln_act_fwd(const float* Y, long ldy, long slab_stride, int ns
 #define LAUNCH(R)                                                                                                    \
   hipLaunchKernelGGL((ln_act_fwd_kernel<R>), dim3(grid), dim3(256), 0, stream, Y, ldy, slab_stride, nslab, bias,     \
                      gamma, beta, B, H, eps, slope, p_drop, seed, xhat, ldx, rstd, out, ldo)
+#define LAUNCH_ROW(C)                                                                                               \
+  hipLaunchKernelGGL((ln_act_fwd_row_kernel<C>), dim3(B), dim3(256), 0, stream, Y, ldy, slab_stride, nslab, bias,    \
+                     gamma, beta, B, H, eps, slope, p_drop, seed, xhat, ldx, rstd, out, ldo)
   if (H <= 64) LAUNCH(1);
-  else if (H <= 256) LAUNCH(4);
-  else if (H <= 1024) LAUNCH(16);
-  else LAUNCH(64);
+  else if (H <= 256) LAUNCH_ROW(1);
+  else if (H <= 1024) LAUNCH_ROW(4);
+  else LAUNCH_ROW(16);
 #undef LAUNCH
+#undef LAUNCH_ROW
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
@@ -189,18 +371,22 @@ extern "C" int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, lo
   SCP_CHECK(B > 0 && H > 0, SCP_ERR_ARG, "scp_ln_act_bwd: B,H must be positive");
   SCP_CHECK(dOut && xhat && dY && partials_ws, SCP_ERR_ARG, "scp_ln_act_bwd: null pointer");
   SCP_CHECK(H <= 4096, SCP_ERR_SHAPE, "scp_ln_act_bwd: H=%d > 4096 unsupported", H);
-  int grid = scp_ln_act_bwd_grid(B);
+  int grid = H <= 64 ? ln_bwd_wave_grid(B) : scp_ln_act_bwd_grid(B);
 #define LAUNCH(R)                                                                                                  \
   hipLaunchKernelGGL((ln_act_bwd_kernel<R>), dim3(grid), dim3(256), 0, stream, dOut, ldo, xhat, ldx, rstd, gamma,   \
                      beta, B, H, slope, p_drop, seed, dY, ldy, partials_ws)
+#define LAUNCH_ROW(C)                                                                                             \
+  hipLaunchKernelGGL((ln_act_bwd_row_kernel<C>), dim3(grid), dim3(256), 0, stream, dOut, ldo, xhat, ldx, rstd,      \
+                     gamma, beta, B, H, slope, p_drop, seed, dY, ldy, partials_ws)
   if (H <= 64) LAUNCH(1);
-  else if (H <= 256) LAUNCH(4);
-  else if (H <= 1024) LAUNCH(16);
-  else LAUNCH(64);
+  else if (H <= 256) LAUNCH_ROW(1);
+  else if (H <= 1024) LAUNCH_ROW(4);
+  else LAUNCH_ROW(16);
 #undef LAUNCH
+#undef LAUNCH_ROW
   SCP_LAUNCH_CHECK();
   int n = 3 * H;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partials_ws, grid, 3, H,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 63) / 64), dim3(64, 16), 0, stream, partials_ws, grid, 3, H,
                      dgamma, dbeta, dbias);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
@@ -250,7 +436,7 @@ extern "C" int scp_colsum(const float* X, long ld, int rows, int cols, float* ou
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, nchunk), dim3(256), 0, stream, X, ld, rows, cols,
                      partials_ws);
   SCP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, partials_ws, nchunk, 1, cols,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((cols + 63) / 64), dim3(64, 16), 0, stream, partials_ws, nchunk, 1, cols,
                      out, (float*)nullptr, (float*)nullptr);
   SCP_LAUNCH_CHECK();
   return SCP_OK;

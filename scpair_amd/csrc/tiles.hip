@@ -13,51 +13,69 @@
 #include "common.h"
 #include "scpair_hip.h"
 
-// one wave per batch row
-__global__ void tiles_count_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-                                   const float* __restrict__ values, const int64_t* __restrict__ rows, int B, int F,
-                                   int32_t* __restrict__ cnt, float* __restrict__ lib, int32_t* __restrict__ nnan) {
-  int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (b >= B) return;
+// one 256-thread workgroup per batch row, four entries in flight per thread
+#define TILE_ROW_THREADS 256
+__global__ __launch_bounds__(TILE_ROW_THREADS) void tiles_count_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
+    const int64_t* __restrict__ rows, int B, int F, int32_t* __restrict__ cnt, float* __restrict__ lib,
+    int32_t* __restrict__ nnan) {
+  __shared__ float red[16];
+  int b = blockIdx.x, tid = threadIdx.x;
   int64_t r = rows[b];
   int64_t e0 = indptr[r], e1 = indptr[r + 1];
-  long base = (long)(b >> 6) * F;
+  int32_t* cb = cnt + (long)(b >> 6) * F;
   float s = 0.f;
   int nn = 0;
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
+  int64_t e = e0 + tid;
+  constexpr int T = TILE_ROW_THREADS;
+  for (; e + 3 * T < e1; e += 4 * T) {
+    int c0 = indices[e], c1 = indices[e + T], c2 = indices[e + 2 * T], c3 = indices[e + 3 * T];
+    float v0 = 1.f, v1 = 1.f, v2 = 1.f, v3 = 1.f;
+    if (values) { v0 = values[e]; v1 = values[e + T]; v2 = values[e + 2 * T]; v3 = values[e + 3 * T]; }
+    atomicAdd(&cb[c0], 1); atomicAdd(&cb[c1], 1); atomicAdd(&cb[c2], 1); atomicAdd(&cb[c3], 1);
+    if (v0 != v0) nn++; else s += v0;
+    if (v1 != v1) nn++; else s += v1;
+    if (v2 != v2) nn++; else s += v2;
+    if (v3 != v3) nn++; else s += v3;
+  }
+  for (; e < e1; e += T) {
     int col = indices[e];
-    atomicAdd(&cnt[base + col], 1);
+    atomicAdd(&cb[col], 1);
     float v = values ? values[e] : 1.f;
-    if (v != v)
-      nn++;
-    else
-      s += v;
+    if (v != v) nn++; else s += v;
   }
   if (lib) {
-    s = wave_sum(s);
-    if (lane == 0) lib[b] = s;
+    s = block_sum(s, red);
+    if (tid == 0) lib[b] = s;
   }
   if (nnan) {
-    nn = (int)wave_sum((float)nn);
-    if (lane == 0 && nn) atomicAdd(nnan, nn);
+    float t = block_sum((float)nn, red);
+    if (tid == 0 && t > 0.f) atomicAdd(nnan, (int)t);
   }
 }
 
-__global__ void tiles_fill_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-                                  const float* __restrict__ values, const int64_t* __restrict__ rows, int B, int F,
-                                  int32_t* __restrict__ start /* ptr + 1 : becomes bucket ends */,
-                                  int32_t* __restrict__ key, float* __restrict__ val) {
-  int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (b >= B) return;
+__global__ __launch_bounds__(TILE_ROW_THREADS) void tiles_fill_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
+    const int64_t* __restrict__ rows, int B, int F, int32_t* __restrict__ start /* ptr + 1 : becomes bucket ends */,
+    int32_t* __restrict__ key, float* __restrict__ val) {
+  int b = blockIdx.x, tid = threadIdx.x;
   int64_t r = rows[b];
   int64_t e0 = indptr[r], e1 = indptr[r + 1];
-  long base = (long)(b >> 6) * F;
+  int32_t* sb = start + (long)(b >> 6) * F;
   int rl = b & 63;
-  for (int64_t e = e0 + lane; e < e1; e += 64) {
+  int64_t e = e0 + tid;
+  constexpr int T = TILE_ROW_THREADS;
+  for (; e + 3 * T < e1; e += 4 * T) {
+    int c0 = indices[e], c1 = indices[e + T], c2 = indices[e + 2 * T], c3 = indices[e + 3 * T];
+    float v0 = 1.f, v1 = 1.f, v2 = 1.f, v3 = 1.f;
+    if (val && values) { v0 = values[e]; v1 = values[e + T]; v2 = values[e + 2 * T]; v3 = values[e + 3 * T]; }
+    int p0 = atomicAdd(&sb[c0], 1), p1 = atomicAdd(&sb[c1], 1), p2 = atomicAdd(&sb[c2], 1), p3 = atomicAdd(&sb[c3], 1);
+    key[p0] = (c0 << 6) | rl; key[p1] = (c1 << 6) | rl; key[p2] = (c2 << 6) | rl; key[p3] = (c3 << 6) | rl;
+    if (val) { val[p0] = v0; val[p1] = v1; val[p2] = v2; val[p3] = v3; }
+  }
+  for (; e < e1; e += T) {
     int col = indices[e];
-    int pos = atomicAdd(&start[base + col], 1);
+    int pos = atomicAdd(&sb[col], 1);
     key[pos] = (col << 6) | rl;
     if (val) val[pos] = values ? values[e] : 1.f;
   }
@@ -151,9 +169,8 @@ extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, co
   // layout: ptr[0] = 0 ; ptr[1 + i] = count(i) -> exclusive scan -> start(i) -> (fill) end(i) = start(i+1)
   SCP_HIP(hipMemsetAsync(ptr, 0, (size_t)(n + 1) * sizeof(int32_t), stream));
   if (nnan) SCP_HIP(hipMemsetAsync(nnan, 0, sizeof(int32_t), stream));
-  int wpb = 4;   // waves per block
-  int grid = (B + wpb - 1) / wpb;
-  hipLaunchKernelGGL(tiles_count_kernel, dim3(grid), dim3(64 * wpb), 0, stream, indptr, indices, values, rows, B, F,
+  int grid = B;
+  hipLaunchKernelGGL(tiles_count_kernel, dim3(grid), dim3(TILE_ROW_THREADS), 0, stream, indptr, indices, values, rows, B, F,
                      ptr + 1, lib, nnan);
   SCP_LAUNCH_CHECK();
   int nblk = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
@@ -165,7 +182,7 @@ extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, co
     hipLaunchKernelGGL(scan_add_kernel, dim3(nblk), dim3(256), 0, stream, ptr + 1, ws, n);
     SCP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(tiles_fill_kernel, dim3(grid), dim3(64 * wpb), 0, stream, indptr, indices, values, rows, B, F,
+  hipLaunchKernelGGL(tiles_fill_kernel, dim3(grid), dim3(TILE_ROW_THREADS), 0, stream, indptr, indices, values, rows, B, F,
                      ptr + 1, key, val);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
