@@ -13,119 +13,62 @@
 #include "common.h"
 #include "scpair_hip.h"
 
-// one 256-thread workgroup per batch row, four entries in flight per thread
-#define TILE_ROW_THREADS 256
-__global__ __launch_bounds__(TILE_ROW_THREADS) void tiles_count_kernel(
-    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
-    const int64_t* __restrict__ rows, int B, int F, int32_t* __restrict__ cnt, float* __restrict__ lib,
-    int32_t* __restrict__ nnan) {
-  __shared__ float red[16];
-  int b = blockIdx.x, tid = threadIdx.x;
+// Build, without global atomics:
+//   1. tiles_bounds_kernel  one thread per (batch row, feature slice): binary search of the slice's first entry in
+//                           the (column-sorted) CSR row; integer atomics add the row's slice length to the
+//                           (cell block, slice) total
+//   2. tiles_scan_kernel    one workgroup: exclusive scan of the (cell block, slice) totals -> slice bases
+//   3. tiles_place_kernel   one workgroup per (slice, cell block): per-feature counts, their scan and the ranks of
+//                           the entries inside a bucket all live in LDS; writes ptr, key and val
+//   4. tiles_rowsum_kernel  lib[b] = row sum (fixed order), NaN count            (only when asked for)
+#define TILE_MAX_SF 2048   // features per slice (LDS histogram), a power of two >= 256
+
+static int tiles_sf(int B, int F) {
+  int ncb = (B + 63) / 64, sf = TILE_MAX_SF;
+  while (sf > 256 && (long)ncb * ((F + sf - 1) / sf) < 768) sf >>= 1;
+  return sf;
+}
+
+__global__ __launch_bounds__(256) void tiles_bounds_kernel(const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ indices,
+                                                           const int64_t* __restrict__ rows, int B, int sf, int nslice,
+                                                           int32_t* __restrict__ bnd /* [B][nslice+1] */,
+                                                           int32_t* __restrict__ tot /* [ncb][nslice], zeroed */) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * (nslice + 1)) return;
+  int b = i / (nslice + 1), sidx = i % (nslice + 1);
   int64_t r = rows[b];
-  int64_t e0 = indptr[r], e1 = indptr[r + 1];
-  int32_t* cb = cnt + (long)(b >> 6) * F;
-  float s = 0.f;
-  int nn = 0;
-  int64_t e = e0 + tid;
-  constexpr int T = TILE_ROW_THREADS;
-  for (; e + 3 * T < e1; e += 4 * T) {
-    int c0 = indices[e], c1 = indices[e + T], c2 = indices[e + 2 * T], c3 = indices[e + 3 * T];
-    float v0 = 1.f, v1 = 1.f, v2 = 1.f, v3 = 1.f;
-    if (values) { v0 = values[e]; v1 = values[e + T]; v2 = values[e + 2 * T]; v3 = values[e + 3 * T]; }
-    atomicAdd(&cb[c0], 1); atomicAdd(&cb[c1], 1); atomicAdd(&cb[c2], 1); atomicAdd(&cb[c3], 1);
-    if (v0 != v0) nn++; else s += v0;
-    if (v1 != v1) nn++; else s += v1;
-    if (v2 != v2) nn++; else s += v2;
-    if (v3 != v3) nn++; else s += v3;
+  int64_t e0 = indptr[r];
+  int len = (int)(indptr[r + 1] - e0);
+  int lo = 0;
+  if (sidx == nslice) {
+    lo = len;
+  } else if (sidx > 0) {
+    int target = sidx * sf, hi = len;
+    const int32_t* ix = indices + e0;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (ix[mid] < target) lo = mid + 1; else hi = mid;
+    }
   }
-  for (; e < e1; e += T) {
-    int col = indices[e];
-    atomicAdd(&cb[col], 1);
-    float v = values ? values[e] : 1.f;
-    if (v != v) nn++; else s += v;
-  }
-  if (lib) {
-    s = block_sum(s, red);
-    if (tid == 0) lib[b] = s;
-  }
-  if (nnan) {
-    float t = block_sum((float)nn, red);
-    if (tid == 0 && t > 0.f) atomicAdd(nnan, (int)t);
-  }
+  bnd[i] = lo;
+  // lo is the start of slice sidx and the end of slice sidx-1
+  int cb = b >> 6;
+  if (sidx < nslice && lo) atomicSub(&tot[cb * nslice + sidx], lo);
+  if (sidx > 0 && lo) atomicAdd(&tot[cb * nslice + sidx - 1], lo);
 }
 
-__global__ __launch_bounds__(TILE_ROW_THREADS) void tiles_fill_kernel(
-    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
-    const int64_t* __restrict__ rows, int B, int F, int32_t* __restrict__ start /* ptr + 1 : becomes bucket ends */,
-    int32_t* __restrict__ key, float* __restrict__ val) {
-  int b = blockIdx.x, tid = threadIdx.x;
-  int64_t r = rows[b];
-  int64_t e0 = indptr[r], e1 = indptr[r + 1];
-  int32_t* sb = start + (long)(b >> 6) * F;
-  int rl = b & 63;
-  int64_t e = e0 + tid;
-  constexpr int T = TILE_ROW_THREADS;
-  for (; e + 3 * T < e1; e += 4 * T) {
-    int c0 = indices[e], c1 = indices[e + T], c2 = indices[e + 2 * T], c3 = indices[e + 3 * T];
-    float v0 = 1.f, v1 = 1.f, v2 = 1.f, v3 = 1.f;
-    if (val && values) { v0 = values[e]; v1 = values[e + T]; v2 = values[e + 2 * T]; v3 = values[e + 3 * T]; }
-    int p0 = atomicAdd(&sb[c0], 1), p1 = atomicAdd(&sb[c1], 1), p2 = atomicAdd(&sb[c2], 1), p3 = atomicAdd(&sb[c3], 1);
-    key[p0] = (c0 << 6) | rl; key[p1] = (c1 << 6) | rl; key[p2] = (c2 << 6) | rl; key[p3] = (c3 << 6) | rl;
-    if (val) { val[p0] = v0; val[p1] = v1; val[p2] = v2; val[p3] = v3; }
-  }
-  for (; e < e1; e += T) {
-    int col = indices[e];
-    int pos = atomicAdd(&sb[col], 1);
-    key[pos] = (col << 6) | rl;
-    if (val) val[pos] = values ? values[e] : 1.f;
-  }
-}
-
-// ---- exclusive scan over int32 (3 phases, 4096 elements per block) ------------------------------
-#define SCAN_CHUNK 4096
-__global__ __launch_bounds__(256) void scan_block_kernel(const int32_t* in, int32_t* out, int32_t* __restrict__ totals,
-                                                         long n) {
-  __shared__ int32_t wsum[4];
-  long base = (long)blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
-  int32_t v[16];
-  int32_t s = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    v[i] = (base + i < n) ? in[base + i] : 0;
-    s += v[i];
-  }
-  // inclusive scan of s over the block
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int32_t inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int32_t t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  int32_t woff = 0;
-  for (int i = 0; i < w; i++) woff += wsum[i];
-  int32_t excl = woff + inc - s;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    if (base + i < n) out[base + i] = excl;
-    excl += v[i];
-  }
-  if (threadIdx.x == 255) totals[blockIdx.x] = woff + inc;
-}
-
-__global__ __launch_bounds__(1024) void scan_totals_kernel(int32_t* __restrict__ totals, int nblk) {
-  // single block, sequential over chunks of 1024
+// exclusive scan of tot[n] in place (single workgroup of 1024); also the two closing ptr entries
+__global__ __launch_bounds__(1024) void tiles_scan_kernel(int32_t* __restrict__ tot, int n, int32_t* __restrict__ ptr_end) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int c0 = 0; c0 < nblk; c0 += 1024) {
+  for (int c0 = 0; c0 < n; c0 += 1024) {
     int i = c0 + threadIdx.x;
-    int32_t s = (i < nblk) ? totals[i] : 0;
-    int32_t inc = s;
+    int32_t v = (i < n) ? tot[i] : 0;
+    int32_t inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       int32_t t = __shfl_up(inc, o, 64);
@@ -136,26 +79,171 @@ __global__ __launch_bounds__(1024) void scan_totals_kernel(int32_t* __restrict__
     int32_t woff = 0;
     for (int k = 0; k < w; k++) woff += wsum[k];
     int32_t carry = carry_s;
-    if (i < nblk) totals[i] = carry + woff + inc - s;
+    if (i < n) tot[i] = carry + woff + inc - v;
     __syncthreads();
     if (threadIdx.x == 1023) carry_s = carry + woff + inc;
     __syncthreads();
   }
+  if (threadIdx.x == 0) {
+    ptr_end[0] = carry_s;
+    ptr_end[1] = carry_s;
+  }
 }
 
-__global__ __launch_bounds__(256) void scan_add_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ totals,
-                                                       long n) {
-  long base = (long)blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
-  int32_t off = totals[blockIdx.x];
+__global__ __launch_bounds__(256) void tiles_place_kernel(const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices,
+                                                          const float* __restrict__ values,
+                                                          const int64_t* __restrict__ rows, int B, int F, int sf,
+                                                          int nslice, const int32_t* __restrict__ bnd,
+                                                          const int32_t* __restrict__ base_of /* scanned tot */,
+                                                          int32_t* __restrict__ ptr, int32_t* __restrict__ key,
+                                                          float* __restrict__ val) {
+  __shared__ int32_t cnt[TILE_MAX_SF];
+  __shared__ int64_t row_e0[64];
+  __shared__ int32_t row_lo[64], row_hi[64];
+  __shared__ int32_t wsum[4];
+  int sl = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int f0 = sl * sf;
+  int nf = min(sf, F - f0);
+  for (int j = tid; j < sf; j += 256) cnt[j] = 0;
+  if (tid < 64) {
+    int b = cb * 64 + tid;
+    int64_t e0 = 0;
+    int lo = 0, hi = 0;
+    if (b < B) {
+      e0 = indptr[rows[b]];
+      lo = bnd[(long)b * (nslice + 1) + sl];
+      hi = bnd[(long)b * (nslice + 1) + sl + 1];
+    }
+    row_e0[tid] = e0; row_lo[tid] = lo; row_hi[tid] = hi;
+  }
+  __syncthreads();
+  // pass 1: per-feature counts.  Wave w owns rows w, w+4, ...; four rows of loads in flight.
+  for (int g = 0; g < 16; g += 4) {
+    int c[4];
 #pragma unroll
-  for (int i = 0; i < 16; i++)
-    if (base + i < n) out[base + i] += off;
+    for (int k = 0; k < 4; k++) {
+      int r = w + 4 * (g + k);
+      int e = row_lo[r] + lane;
+      c[k] = (e < row_hi[r]) ? indices[row_e0[r] + e] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (c[k] >= 0) atomicAdd(&cnt[c[k] - f0], 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int r = w + 4 * (g + k);
+      for (int e = row_lo[r] + 64 + lane; e < row_hi[r]; e += 64) atomicAdd(&cnt[indices[row_e0[r] + e] - f0], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of cnt[0..sf): thread t owns E consecutive features
+  int E = sf >> 8;
+  int32_t loc[TILE_MAX_SF / 256];
+  int32_t s = 0;
+#pragma unroll
+  for (int q = 0; q < TILE_MAX_SF / 256; q++) {
+    loc[q] = (q < E) ? cnt[tid * E + q] : 0;
+    s += loc[q];
+  }
+  int32_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int32_t excl = inc - s;
+  for (int k = 0; k < w; k++) excl += wsum[k];
+  int32_t base = base_of[cb * nslice + sl];
+  int32_t* pout = ptr + (long)cb * F + f0;
+#pragma unroll
+  for (int q = 0; q < TILE_MAX_SF / 256; q++) {
+    if (q < E) {
+      int j = tid * E + q;
+      cnt[j] = excl;               // becomes the bucket's running write position
+      if (j < nf) pout[j] = base + excl;
+      excl += loc[q];
+    }
+  }
+  __syncthreads();
+  // pass 2: place
+  int rl_base = 0;
+  for (int g = 0; g < 16; g += 4) {
+    int c[4];
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int r = w + 4 * (g + k);
+      int e = row_lo[r] + lane;
+      bool ok = e < row_hi[r];
+      c[k] = ok ? indices[row_e0[r] + e] : -1;
+      v[k] = (ok && val && values) ? values[row_e0[r] + e] : 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int r = w + 4 * (g + k);
+      if (c[k] >= 0) {
+        int pos = base + atomicAdd(&cnt[c[k] - f0], 1);
+        key[pos] = (c[k] << 6) | r;
+        if (val) val[pos] = v[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int r = w + 4 * (g + k);
+      for (int e = row_lo[r] + 64 + lane; e < row_hi[r]; e += 64) {
+        int col = indices[row_e0[r] + e];
+        int pos = base + atomicAdd(&cnt[col - f0], 1);
+        key[pos] = (col << 6) | r;
+        if (val) val[pos] = values ? values[row_e0[r] + e] : 1.f;
+      }
+    }
+  }
+  (void)rl_base;
+}
+
+// lib[b] = sum of the row's values (NaNs skipped and counted); one workgroup per row, fixed order
+__global__ __launch_bounds__(256) void tiles_rowsum_kernel(const int64_t* __restrict__ indptr,
+                                                           const float* __restrict__ values,
+                                                           const int64_t* __restrict__ rows, int B,
+                                                           float* __restrict__ lib, int32_t* __restrict__ nnan) {
+  __shared__ float red[16];
+  int b = blockIdx.x, tid = threadIdx.x;
+  int64_t r = rows[b];
+  int64_t e0 = indptr[r], e1 = indptr[r + 1];
+  float s = 0.f;
+  int nn = 0;
+  if (values) {
+    int64_t e = e0 + tid;
+    for (; e + 768 < e1; e += 1024) {
+      float v0 = values[e], v1 = values[e + 256], v2 = values[e + 512], v3 = values[e + 768];
+      if (v0 != v0) nn++; else s += v0;
+      if (v1 != v1) nn++; else s += v1;
+      if (v2 != v2) nn++; else s += v2;
+      if (v3 != v3) nn++; else s += v3;
+    }
+    for (; e < e1; e += 256) {
+      float v = values[e];
+      if (v != v) nn++; else s += v;
+    }
+    s = block_sum(s, red);
+  } else {
+    s = (float)(e1 - e0);
+  }
+  if (lib && tid == 0) lib[b] = s;
+  if (nnan && values) {
+    float t = block_sum((float)nn, red);
+    if (tid == 0 && t > 0.f) atomicAdd(nnan, (int)t);
+  }
 }
 
 extern "C" long scp_tiles_ptr_len(int B, int F) { return (long)((B + 63) / 64) * F + 2; }
 extern "C" long scp_tiles_ws_len(int B, int F) {
-  long n = (long)((B + 63) / 64) * F + 1;
-  return (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
+  int sf = tiles_sf(B, F);
+  long nslice = (F + sf - 1) / sf, ncb = (B + 63) / 64;
+  return (long)B * (nslice + 1) + ncb * nslice + 2;
 }
 
 extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* rows,
@@ -165,25 +253,24 @@ extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, co
   SCP_CHECK(B > 0 && F > 0, SCP_ERR_ARG, "scp_tiles_build: B and F must be positive (%d,%d)", B, F);
   SCP_CHECK(indptr && indices && rows && ptr && key && ws, SCP_ERR_ARG, "scp_tiles_build: null pointer");
   SCP_CHECK(F < (1 << 25), SCP_ERR_SHAPE, "scp_tiles_build: F=%d exceeds the 2^25 key range", F);
-  long n = (long)((B + 63) / 64) * F + 1;   // buckets + 1
-  // layout: ptr[0] = 0 ; ptr[1 + i] = count(i) -> exclusive scan -> start(i) -> (fill) end(i) = start(i+1)
-  SCP_HIP(hipMemsetAsync(ptr, 0, (size_t)(n + 1) * sizeof(int32_t), stream));
+  int sf = tiles_sf(B, F);
+  int nslice = (F + sf - 1) / sf, ncb = (B + 63) / 64;
+  int32_t* bnd = ws;
+  int32_t* tot = ws + (long)B * (nslice + 1);
+  SCP_HIP(hipMemsetAsync(tot, 0, (size_t)ncb * nslice * sizeof(int32_t), stream));
   if (nnan) SCP_HIP(hipMemsetAsync(nnan, 0, sizeof(int32_t), stream));
-  int grid = B;
-  hipLaunchKernelGGL(tiles_count_kernel, dim3(grid), dim3(TILE_ROW_THREADS), 0, stream, indptr, indices, values, rows, B, F,
-                     ptr + 1, lib, nnan);
+  int nthr = B * (nslice + 1);
+  hipLaunchKernelGGL(tiles_bounds_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, indptr, indices, rows, B, sf,
+                     nslice, bnd, tot);
   SCP_LAUNCH_CHECK();
-  int nblk = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
-  hipLaunchKernelGGL(scan_block_kernel, dim3(nblk), dim3(256), 0, stream, ptr + 1, ptr + 1, ws, n);
+  hipLaunchKernelGGL(tiles_scan_kernel, dim3(1), dim3(1024), 0, stream, tot, ncb * nslice, ptr + (long)ncb * F);
   SCP_LAUNCH_CHECK();
-  if (nblk > 1) {
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, stream, ws, nblk);
-    SCP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nblk), dim3(256), 0, stream, ptr + 1, ws, n);
+  hipLaunchKernelGGL(tiles_place_kernel, dim3(nslice, ncb), dim3(256), 0, stream, indptr, indices, values, rows, B, F,
+                     sf, nslice, bnd, tot, ptr, key, val);
+  SCP_LAUNCH_CHECK();
+  if (lib || nnan) {
+    hipLaunchKernelGGL(tiles_rowsum_kernel, dim3(B), dim3(256), 0, stream, indptr, values, rows, B, lib, nnan);
     SCP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(tiles_fill_kernel, dim3(grid), dim3(TILE_ROW_THREADS), 0, stream, indptr, indices, values, rows, B, F,
-                     ptr + 1, key, val);
-  SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

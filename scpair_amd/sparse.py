@@ -132,7 +132,7 @@ class BatchTiles:
         self.key = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)
         self.val = None if csr.values is None else torch.empty(max(self.nnz, 1), dtype=torch.float32, device=dev)
         self.lib = torch.empty(self.B, dtype=torch.float32, device=dev) if want_lib else None
-        self.nnan = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.nnan = torch.empty(1, dtype=torch.int32, device=dev)   # cleared by scp_tiles_build
         ws = torch.empty(L.scp_tiles_ws_len(self.B, self.F), dtype=torch.int32, device=dev)
         _lib.check(L.scp_tiles_build(_lib.ptr(csr.indptr), _lib.ptr(csr.indices), _lib.ptr(csr.values),
                                      _lib.ptr(rows_dev), self.B, self.F, _lib.ptr(self.ptr), _lib.ptr(self.key),
