@@ -94,7 +94,7 @@ __device__ __forceinline__ void img_put(__bf16* img, int rows, int ld, int row, 
 }
 
 template <int NS, int KP, int NPT, int MODE>
-__global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dec_kernel(DecArgs g) {
   constexpr bool IS_BER = (MODE == MODE_BER_TRAIN || MODE == MODE_BER_EVAL);
   constexpr bool TRAIN = (MODE == MODE_BER_TRAIN || MODE == MODE_NB_GRAD);
   constexpr bool NEED_LABELS = (MODE != MODE_NB_STATS);
@@ -140,27 +140,53 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
   double loss_acc = 0.0;
 
   // ---- software pipeline state: operands of the UPCOMING iteration live in registers -------------------
-  constexpr int WPT = FT * KP / 256;            // elements per thread of a 64 x KP operand block
+  // Staging map of a 64 x KP operand block: thread -> (row sp = tid/4, columns [sq*KQ, sq*KQ + KQ)); one base
+  // address per operand and immediate offsets keep the address arithmetic out of the register file.
+  constexpr int KQ = KP / 4;
   constexpr int EPF = 2;                        // label entries prefetched per thread
-  float wreg[WPT], hreg[WPT];
+  const int sp = tid >> 2, sq = tid & 3;
+  const bool vec_w = ((g.K & 3) == 0) && ((g.ldw & 3) == 0) && ((((uintptr_t)g.W) & 15) == 0);
+  const bool vec_h = ((g.K & 3) == 0) && ((g.ldh & 3) == 0) && ((((uintptr_t)g.h) & 15) == 0);
+  float wreg[KQ], hreg[KQ];
   int ekey[EPF];
   float evl[EPF];
   int ep0 = 0, ep1 = 0;                         // entry range of the upcoming iteration
   int pn0 = 0, pn1 = 0;                         // entry range of the iteration after it (ptr loaded one step earlier)
-  auto load_w = [&](int f0n) {
+  auto load_rows = [&](float* reg, const float* base, long ld, int row, int nrows, bool vec) {
+    const float* src = base + (long)row * ld + sq * KQ;
+    const bool rok = row < nrows;
+    if (vec) {
 #pragma unroll
-    for (int j = 0; j < WPT; j++) {
-      int idx = tid + 256 * j;
-      int p = idx / KP, k = idx % KP;
-      wreg[j] = (f0n + p < g.F && k < g.K) ? g.W[(long)(f0n + p) * g.ldw + k] : 0.f;
+      for (int i = 0; i < KQ / 4; i++) {
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (rok && sq * KQ + 4 * i < g.K) v = *(const float4*)(src + 4 * i);
+        reg[4 * i] = v.x; reg[4 * i + 1] = v.y; reg[4 * i + 2] = v.z; reg[4 * i + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KQ; i++) reg[i] = (rok && sq * KQ + i < g.K) ? src[i] : 0.f;
     }
   };
-  auto load_h = [&](int c0n) {
+  auto load_w = [&](int f0n) { load_rows(wreg, g.W, g.ldw, f0n + sp, g.F, vec_w); };
+  auto load_h = [&](int c0n) { load_rows(hreg, g.h, g.ldh, c0n + sp, g.B, vec_h); };
+  // registers -> row-major image [NS][64][LDK_] (8-byte stores) and, when training, the transposed image [NS][KP][LDZ]
+  auto put_rows = [&](const float* reg, __bf16* img, __bf16* imgT) {
+    __bf16 tt[KQ][3];
 #pragma unroll
-    for (int j = 0; j < WPT; j++) {
-      int idx = tid + 256 * j;
-      int c = idx / KP, k = idx % KP;
-      hreg[j] = (c0n + c < g.B && k < g.K) ? g.h[(long)(c0n + c) * g.ldh + k] : 0.f;
+    for (int i = 0; i < KQ; i++) bf16_split<NS>(reg[i], tt[i]);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; s2++) {
+#pragma unroll
+      for (int i = 0; i < KQ / 4; i++) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = tt[4 * i + j][s2];
+        *(bf16x4*)&img[(s2 * 64 + sp) * LDK_ + sq * KQ + 4 * i] = o;
+      }
+      if (TRAIN) {
+#pragma unroll
+        for (int i = 0; i < KQ; i++) imgT[(s2 * KP + sq * KQ + i) * LDZ + sp] = tt[i][s2];
+      }
     }
   };
   auto load_ptr = [&](int cbx, int f0x) {
@@ -209,13 +235,7 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
       __syncthreads();                            // previous iteration's readers are done
       if (t == 0) {
         // ---- h block (both layouts) and the per-cell inputs, from the prefetch registers ---------------
-#pragma unroll
-        for (int j = 0; j < WPT; j++) {
-          int idx = tid + 256 * j;
-          int c = idx / KP, k = idx % KP;
-          img_put<NS>(hA, CB, LDK_, c, k, hreg[j]);
-          if (TRAIN) img_put<NS>(hT, KP, LDZ, k, c, hreg[j]);
-        }
+        put_rows(hreg, hA, hT);
         if (tid < CB) {
           int c = c0 + tid;
           bool ok = c < g.B;
@@ -230,13 +250,7 @@ __global__ __launch_bounds__(256) void dec_kernel(DecArgs g) {
         }
       }
       // ---- W tile (both layouts) from the prefetch registers, clear label tile ---------------------
-#pragma unroll
-      for (int j = 0; j < WPT; j++) {
-        int idx = tid + 256 * j;
-        int p = idx / KP, k = idx % KP;
-        img_put<NS>(WB, FT, LDK_, p, k, wreg[j]);
-        if (TRAIN) img_put<NS>(WT, KP, LDZ, k, p, wreg[j]);
-      }
+      put_rows(wreg, WB, WT);
       if (NEED_LABELS) {
         float4 z4 = {0.f, 0.f, 0.f, 0.f};
         for (int idx = tid; idx < CB * FT / 4; idx += 256) ((float4*)ytile)[idx] = z4;
