@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   float* rred = rowv + 3 * CB;                    // [2][2][64] per-cell partial reductions
   float* cred = ytile;                            // [2][NPT][3][64] per-feature partials; aliases ytile (used after the loops)
   __shared__ double dred[8];
+  __shared__ int tflag;                           // label tile holds a value other than 0/1 (or NaN)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, hq = lane >> 5;
@@ -228,10 +229,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       racc1[e] = 0.f;
     }
 
-#pragma unroll
+    // The tile loop stays rolled (one copy of the body keeps the register budget at 2 waves/SIMD): the tile in
+    // flight always accumulates into slot 0 and the per-tile accumulators rotate by one slot per iteration, so
+    // after the NPT iterations of a cell block every slot is back in place.
+#pragma unroll 1
     for (int t = 0; t < NPT; t++) {
       const int f0 = f_chunk0 + t * FT;
-      if (t >= ntl) break;                        // uniform
+      if (t < ntl) {                              // uniform
       __syncthreads();                            // previous iteration's readers are done
       if (t == 0) {
         // ---- h block (both layouts) and the per-cell inputs, from the prefetch registers ---------------
@@ -254,15 +258,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       if (NEED_LABELS) {
         float4 z4 = {0.f, 0.f, 0.f, 0.f};
         for (int idx = tid; idx < CB * FT / 4; idx += 256) ((float4*)ytile)[idx] = z4;
+        if (tid == 0) tflag = 0;
         __syncthreads();
+        bool odd = false;
 #pragma unroll
         for (int i = 0; i < EPF; i++)
-          if (ekey[i] >= 0) ytile[(ekey[i] & 63) * FT + ((ekey[i] >> 6) - f0)] = evl[i];
+          if (ekey[i] >= 0) {
+            ytile[(ekey[i] & 63) * FT + ((ekey[i] >> 6) - f0)] = evl[i];
+            odd |= !(evl[i] == 1.f);
+          }
         for (int e = ep0 + tid + 256 * EPF; e < ep1; e += 256) {
           int key = g.t_key[e];
           float v = g.t_val ? g.t_val[e] : 1.f;
           ytile[(key & 63) * FT + ((key >> 6) - f0)] = v;
+          odd |= !(v == 1.f);
         }
+        if (IS_BER && odd) tflag = 1;
       }
       // ---- issue the loads of the NEXT iteration; they complete under the MFMA + epilogue below -------
       {
@@ -312,6 +323,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       if (!IS_BER && g.theta_param && f_ok) thcol = exp_<FAST>(g.theta_param[f]);
       float dzv[16];
       float lsum = 0.f;     // fp32 partial of this tile, folded into the fp64 accumulator once per tile
+      // Bernoulli, interior tile with 0/1 labels only: no bounds / NaN / soft-label handling (same algebra)
+      const bool ber_fast = IS_BER && (f0 + FT <= g.F) && (c0 + CB <= g.B) && (tflag == 0);
+      if (ber_fast) {
+        float su = 0.f, sd = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int cl = ti * 32 + acc_row(e, lane);
+          float px = sigm_<FAST>(acc[e] + bcol);
+          float sr = rowv[cl];
+          float q = px * sr * fcol;
+          float omq = 1.f - q;
+          float yv = ytile[cl * FT + fl];
+          float arg = (yv == 0.f) ? omq : q;
+          lsum -= fmaxf(log_<FAST>(arg), -100.f);
+          if (TRAIN) {
+            float u = div_<FAST>(q - yv, fmaxf(q * omq, 1e-12f)) * inv_n * q;     // dL/dq * q
+            float d = u * (1.f - px);
+            dzv[e] = d;
+            racc0[e] += u * (1.f - sr);
+            su += u;
+            sd += d;
+          }
+        }
+        if (TRAIN) {
+          dfs_acc[0] += su * (1.f - fcol);
+          db_acc[0] += sd;
+        }
+      } else
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int cl = ti * 32 + acc_row(e, lane);
@@ -337,8 +376,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
               float t1 = dq * px;
               dzv[e] = t1 * sr * fcol * (1.f - px);
               racc0[e] += t1 * fcol * sr * (1.f - sr);
-              dfs_acc[t] += t1 * sr * fcol * (1.f - fcol);
-              db_acc[t] += dzv[e];
+              dfs_acc[0] += t1 * sr * fcol * (1.f - fcol);
+              db_acc[0] += dzv[e];
             }
           }
         } else {
@@ -376,13 +415,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
               float dap = mu * gmu - scale * T;
               float da = dap * fcol;
               if (g.theta_param)
-                dth_acc[t] += -inv_n * gth * th;
+                dth_acc[0] += -inv_n * gth * th;
               else
                 da += gth * th;
               float d = (zz > 0.f) ? -inv_n * da : 0.f;
               dzv[e] = d;
-              db_acc[t] += d;
-              dfs_acc[t] += -inv_n * dap * a_ * fcol * (1.f - fcol);
+              db_acc[0] += d;
+              dfs_acc[0] += -inv_n * dap * a_ * fcol * (1.f - fcol);
             }
           }
         }
@@ -430,11 +469,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
               for (int sb = 0; sb < NS; sb++)
                 if (sa + sb < NS) {
-                  accW[t] = mfma32(a[sa], b[sb], accW[t]);
+                  accW[0] = mfma32(a[sa], b[sb], accW[0]);
                   accH = mfma32(a2[sa], b2[sb], accH);
                 }
           }
         }
+      }
+      }  // t < ntl
+      if (TRAIN) {
+        f32x16 w0 = accW[0];
+        float b0 = db_acc[0], s0 = dfs_acc[0], h0 = dth_acc[0];
+#pragma unroll
+        for (int q = 0; q + 1 < NPT; q++) {
+          accW[q] = accW[q + 1];
+          db_acc[q] = db_acc[q + 1];
+          dfs_acc[q] = dfs_acc[q + 1];
+          dth_acc[q] = dth_acc[q + 1];
+        }
+        accW[NPT - 1] = w0;
+        db_acc[NPT - 1] = b0; dfs_acc[NPT - 1] = s0; dth_acc[NPT - 1] = h0;
       }
     }  // feature tiles
 
@@ -544,7 +597,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 }
 
 
-#define DEC_NPT 4
+#define DEC_NPT 2
 
 template <int NS, int KP>
 static size_t dec_smem() {
