@@ -63,10 +63,13 @@ __device__ __forceinline__ void store_split8(__bf16* S, int row, int kcol, const
   }
 }
 
-template <int NS>
-__device__ __forceinline__ void load_dense_tile(__bf16* S, const float* __restrict__ p, long sr, long sk, int vec,
-                                                int r0, int rows, int k0, int kend) {
-  for (int c = threadIdx.x; c < TM * (TK / 8); c += 256) {
+// Dense operand staging is split in two so the global loads of a whole 128 x 64 tile (4 chunks of 8 values per
+// thread) are in flight together and, for the next K-step, overlap the MFMAs of the current one.
+__device__ __forceinline__ void fetch_dense_tile(float (&v)[4][8], const float* __restrict__ p, long sr, long sk, int vec,
+                                                 int r0, int rows, int k0, int kend) {
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    int c = threadIdx.x + 256 * it;
     int row, kc;
     if (sk == 1) {
       row = c >> 3;
@@ -75,23 +78,38 @@ __device__ __forceinline__ void load_dense_tile(__bf16* S, const float* __restri
       row = c & (TM - 1);
       kc = c >> 7;
     }
-    float v[8];
     int gr = r0 + row, gk = k0 + kc * 8;
     if (gr < rows && gk < kend) {
       const float* q = p + (long)gr * sr + (long)gk * sk;
       if (vec && gk + 8 <= kend) {
         float4 x = *(const float4*)q, y = *(const float4*)(q + 4);
-        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-        v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+        v[it][0] = x.x; v[it][1] = x.y; v[it][2] = x.z; v[it][3] = x.w;
+        v[it][4] = y.x; v[it][5] = y.y; v[it][6] = y.z; v[it][7] = y.w;
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = (gk + j < kend) ? q[(long)j * sk] : 0.f;
+        for (int j = 0; j < 8; j++) v[it][j] = (gk + j < kend) ? q[(long)j * sk] : 0.f;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; j++) v[j] = 0.f;
+      for (int j = 0; j < 8; j++) v[it][j] = 0.f;
     }
-    store_split8<NS>(S, row, kc * 8, v);
+  }
+}
+
+template <int NS>
+__device__ __forceinline__ void put_dense_tile(__bf16* S, const float (&v)[4][8], long sk) {
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    int c = threadIdx.x + 256 * it;
+    int row, kc;
+    if (sk == 1) {
+      row = c >> 3;
+      kc = c & 7;
+    } else {
+      row = c & (TM - 1);
+      kc = c >> 7;
+    }
+    store_split8<NS>(S, row, kc * 8, v[it]);
   }
 }
 
@@ -170,14 +188,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][jj][e] = 0.f;
 
+  float ra[AKIND == 0 ? 4 : 1][8], rb[BKIND == 0 ? 4 : 1][8];
+  auto fetch = [&](int k0) {
+    int kend = min(k0 + TK, kend_all);
+    if constexpr (AKIND == 0) fetch_dense_tile(ra, g.A, g.a_sr, g.a_sk, g.a_vec, m0, g.M, k0, kend);
+    if constexpr (BKIND == 0) fetch_dense_tile(rb, g.B, g.b_sr, g.b_sk, g.b_vec, n0, g.N, k0, kend);
+  };
+  if (kbeg < kend_all) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend_all; k0 += TK) {
     int kend = min(k0 + TK, kend_all);
-    if (AKIND == 0)
-      load_dense_tile<NS>(As, g.A, g.a_sr, g.a_sk, g.a_vec, m0, g.M, k0, kend);
+    if constexpr (AKIND == 0)
+      put_dense_tile<NS>(As, ra, g.a_sk);
     else
       zero_tile<NS>(As);
-    if (BKIND == 0)
-      load_dense_tile<NS>(Bs, g.B, g.b_sr, g.b_sk, g.b_vec, n0, g.N, k0, kend);
+    if constexpr (BKIND == 0)
+      put_dense_tile<NS>(Bs, rb, g.b_sk);
     else
       zero_tile<NS>(Bs);
     if (AKIND == 1 || BKIND == 1) {
@@ -186,6 +211,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       if (BKIND == 1) scatter_sparse_B<NS>(Bs, g, n0, k0);
     }
     __syncthreads();
+    if (k0 + TK < kend_all) fetch(k0 + TK);       // in flight during the MFMAs below
 #pragma unroll
     for (int kk = 0; kk < TK / 16; kk++) {
       bf16x8 af[NS][2], bfr[NS][2];
