@@ -47,6 +47,7 @@ int scp_spmm_dw(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t
  * as bf16 [N][ldt] (scp_transpose_bf16) */
 int scp_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
 int scp_transpose_bf16(const float* src, int rows, int cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
+int scp_spmm_fwd_bf16_min_split(int F);   /* smallest nsplit scp_spmm_fwd_bf16 accepts for F features */
 int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
                       const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream);
 int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,

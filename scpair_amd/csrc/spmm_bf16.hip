@@ -11,6 +11,7 @@
 //   * the next K-step's dense tile and sparse entries are prefetched into registers while the MFMAs of the
 //     current step run.
 // The sparse operand is densified into LDS from the minibatch tile list exactly as in gemm.hip.
+#include <type_traits>
 #include "common.h"
 #include "scpair_hip.h"
 
@@ -32,14 +33,35 @@ __device__ __forceinline__ uint4 ld16(const __bf16* p, bool ok) {
   return ok ? *(const uint4*)p : z;
 }
 
+// A load the compiler's memory-wait bookkeeping does not see: issued and awaited inside one asm statement.
+// The K loop of the forward kernel keeps three K-steps of compiler-tracked loads in flight; the waitcnt pass turns
+// any *visible* load on a rare side path (a loop of unknown trip count) into a full drain (vmcnt(0)) at the next
+// control-flow merge, which would serialise the prefetch.  The rare overflow path therefore uses this helper.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t gload_b32_sync(const void* p) {
+  uint32_t v;
+  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // forward: tile 256 cells x 128 hidden x 64 features, 8 waves as 4 (cells) x 2 (hidden)
+//
+// One barrier per K-step.  LDS holds three A (densified cells x features) buffers and two B (weights) buffers:
+// while the MFMAs of step i read A[i%3] / B[i%2], the same step writes the operands of step i+1 (B tile from
+// registers, sparse entries scattered into A[(i+1)%3]) and re-zeroes just the positions step i-1 had scattered
+// into A[(i-1)%3] (its keys are kept in registers), so the A buffers are never cleared wholesale inside the loop.
+// The global loads run three steps ahead of their use in registers (stage r holds steps r, r+3, ...).
 // ------------------------------------------------------------------------------------------------------
+template <bool HASVAL>
 __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
+  constexpr int EPT = HASVAL ? 4 : 2;             // sparse entries held per thread and stage
+  constexpr int ASZ = 256 * LDK, BSZ = 128 * LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* As = (__bf16*)smem_raw;        // [256][LDK]
-  __bf16* Bs = As + 256 * LDK;           // [128][LDK]
-  int* ptrs = (int*)(Bs + 128 * LDK);    // [4][PCH + 1] entry offsets of the next PCH K-steps, per cell block
+  __bf16* As = (__bf16*)smem_raw;        // [3][256][LDK]
+  __bf16* Bs = As + 3 * ASZ;             // [2][128][LDK]
+  int* ptrs = (int*)(Bs + 2 * BSZ);      // [4][PCH + 1] entry offsets of the next PCH K-steps, per cell block
+  __shared__ int ovf[3];                 // step+1 of a step whose A buffer holds entries beyond the per-thread slots
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, hq = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -53,12 +75,10 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
   const int m0 = m_tile * 256, n0 = n_tile * 128;
   const int kbeg = split * g.ksplit_len;
   const int kend_all = min(g.F, kbeg + g.ksplit_len);
+  const int nstep = (kend_all - kbeg + 63) >> 6;
 
   // sparse side: 4 cell blocks, 128 threads each
   const int cbl = tid >> 7, tl = tid & 127;
-  const int cb = (m0 >> 6) + cbl;
-  const bool cb_ok = cb < g.ncb;
-  const long pbase = (long)cb * g.F;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -68,94 +88,167 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][jj][e] = 0.f;
 
-  uint4 breg[2];
-  int ekey[PF];
-  float eval_[PF];
-  int p0 = 0, p1 = 0;
+  u32x4 breg[3][2];
+  uint32_t ekey[3][EPT], eval_[3][HASVAL ? EPT : 1];
+  int p0[3], p1[3];
+  int skey[3][EPT];                               // LDS offsets this thread scattered for step j (slot j%3), -1 = none
+  const int brow = tid >> 3, bkc = tid & 7;       // B tile chunk of this thread (and +64 rows for the second one)
 
-  auto prefetch = [&](int k0) {
-    int kend = min(k0 + 64, kend_all);
+  auto prefetch = [&](u32x4 (&br)[2], uint32_t (&ek)[EPT], uint32_t (&ev)[HASVAL ? EPT : 1], int& q0, int& q1,
+                      int step) {
+    const int k0 = kbeg + 64 * step;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      int c = tid + 512 * i;
-      int row = c >> 3, kc = c & 7;
-      int n = n0 + row, k = k0 + kc * 8;
-      breg[i] = ld16(g.D + (long)n * g.ldd + k, n < g.N && k < g.ldd);
+      int n = min(n0 + brow + 64 * i, g.N - 1);
+      long k = min((long)k0 + bkc * 8, g.ldd - 8);
+      br[i] = *(const u32x4*)(g.D + (long)n * g.ldd + k);
     }
     {
-      int si = ((k0 - kbeg) >> 6) % PCH;
-      p0 = ptrs[cbl * (PCH + 1) + si];
-      p1 = ptrs[cbl * (PCH + 1) + si + 1];
+      int si = step % PCH;
+      q0 = ptrs[cbl * (PCH + 1) + si];
+      q1 = ptrs[cbl * (PCH + 1) + si + 1];
     }
+    const int elast = max(q1 - 1, 0);
 #pragma unroll
-    for (int i = 0; i < PF; i++) {
-      int e = p0 + tl + 128 * i;
-      ekey[i] = (e < p1) ? g.key[e] : -1;
-      eval_[i] = (e < p1 && g.val) ? g.val[e] : 1.f;
+    for (int i = 0; i < EPT; i++) {
+      int e = min(q0 + tl + 128 * i, elast);
+      ek[i] = (uint32_t)g.key[e];
+      if constexpr (HASVAL) ev[i] = __float_as_uint(g.val[e]);
     }
   };
 
-  // entry offsets of K-steps [c0, c0 + PCH] of this slice -> LDS (one global latency per PCH steps instead of a
+  // entry offsets of steps [first, first + PCH] of this slice -> LDS (one global latency per PCH steps instead of a
   // dependent ptr -> key chain in every step)
-  auto load_ptrs = [&](int kfirst) {
+  auto load_ptrs = [&](int first) {
     for (int i = tid; i < 4 * (PCH + 1); i += 512) {
       int c = i / (PCH + 1), sidx = i % (PCH + 1);
       int cbx = (m0 >> 6) + c;
-      int k = min(kfirst + sidx * 64, kend_all);
+      int k = min(kbeg + (first + sidx) * 64, kend_all);
       ptrs[i] = (cbx < g.ncb) ? g.ptr[(long)cbx * g.F + k] : 0;
     }
   };
-  if (kbeg < kend_all) {
-    load_ptrs(kbeg);
+  // registers of one stage -> LDS operands of `step`
+  auto stage_out = [&](const u32x4 (&br)[2], const uint32_t (&ek)[EPT], const uint32_t (&ev)[HASVAL ? EPT : 1], int q0,
+                       int q1, int step, int (&sk)[EPT]) {
+    const int k0 = kbeg + 64 * step;
+    __bf16* Ad = As + (step % 3) * ASZ;
+    __bf16* Bd = Bs + (step & 1) * BSZ;
+    const bool kin = (long)k0 + bkc * 8 < g.ldd;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      u32x4 v = br[i];
+      if (!(kin && n0 + brow + 64 * i < g.N)) v = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)&Bd[(brow + 64 * i) * LDK + bkc * 8] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      sk[i] = -1;
+      if (q0 + tl + 128 * i < q1) {
+        int key = (int)ek[i];
+        float v = 1.f;
+        if constexpr (HASVAL) v = __uint_as_float(ev[i]);
+        int off = (cbl * 64 + (key & 63)) * LDK + ((key >> 6) - k0);
+        Ad[off] = (__bf16)v;
+        sk[i] = off;
+      }
+    }
+    if (q0 + 128 * EPT < q1) {                    // overflow of a dense (cell block, K-step): rare, uniform per wave
+      if (tl == 0) ovf[step % 3] = step + 1;
+      for (int e = q0 + tl + 128 * EPT; e < q1; e += 128) {
+        int key = (int)gload_b32_sync(g.key + e);
+        float v = 1.f;
+        if constexpr (HASVAL) v = __uint_as_float(gload_b32_sync(g.val + e));
+        Ad[(cbl * 64 + (key & 63)) * LDK + ((key >> 6) - k0)] = (__bf16)v;
+      }
+    }
+  };
+  auto zero_A = [&](int buf) {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4* q = (u32x4*)(As + buf * ASZ);
+    for (int i = tid; i < ASZ * 2 / 16; i += 512) q[i] = z;
+  };
+  // undo the scatter of `step` (whose MFMAs are done): its buffer is all zero again afterwards
+  auto unscatter = [&](int step, const int (&sk)[EPT]) {
+    __bf16* Ad = As + (step % 3) * ASZ;
+    // the tag was written two barriers ago (when the step was staged) and the slot is next written one barrier
+    // from now, so every thread reads the same value; a stale tag of step-3 never matches
+    if (ovf[step % 3] == step + 1) {
+      zero_A(step % 3);
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPT; i++)
+        if (sk[i] >= 0) Ad[sk[i]] = (__bf16)0.f;
+    }
+  };
+  if (nstep > 0) {
+    load_ptrs(0);
+    zero_A(0);
+    zero_A(1);
+    zero_A(2);
+    if (tid < 3) ovf[tid] = 0;
     __syncthreads();
-    prefetch(kbeg);
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+      if (s < nstep) prefetch(breg[s], ekey[s], eval_[s], p0[s], p1[s], s);
+    stage_out(breg[0], ekey[0], eval_[0], p0[0], p1[0], 0, skey[0]);
+    if (3 < nstep) prefetch(breg[0], ekey[0], eval_[0], p0[0], p1[0], 3);
+    __syncthreads();
   }
-  for (int k0 = kbeg; k0 < kend_all; k0 += 64) {
-    // zero A, write B
-    {
-      uint4 z = {0u, 0u, 0u, 0u};
-      uint4* q = (uint4*)As;
-      for (int i = tid; i < 256 * LDK * 2 / 16; i += 512) q[i] = z;
+  // One K-step.  FULL = every neighbour the step touches exists (steps i-1 .. i+4), so the body is straight-line:
+  // the hot loop below consists of FULL steps only, which lets the compiler wait for exactly the oldest of the
+  // three load stages in flight instead of draining all of them.
+  auto k_step = [&](auto full_c, auto s_c, int i) {
+    constexpr bool FULL = decltype(full_c)::value;
+    constexpr int s = decltype(s_c)::value;       // i % 3
+    constexpr int s1 = (s + 1) % 3, s2 = (s + 2) % 3;
+    const __bf16* Ar = As + s * ASZ;
+    const __bf16* Br = Bs + (i & 1) * BSZ;
+    bf16x8 af[4][2], bfr[4][2];
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        int c = tid + 512 * i;
-        int row = c >> 3, kc = c & 7;
-        *(uint4*)&Bs[row * LDK + kc * 8] = breg[i];
+    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        af[kk][q] = *(const bf16x8*)&Ar[(wm * 64 + q * 32 + r) * LDK + kk * 16 + hq * 8];
+        bfr[kk][q] = *(const bf16x8*)&Br[(wn * 64 + q * 32 + r) * LDK + kk * 16 + hq * 8];
       }
-    }
+    auto mfma_group = [&](int kk) {
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) acc[q][jj] = mfma32(af[kk][q], bfr[kk][jj], acc[q][jj]);
+    };
+    // ---- operands of step i+1 (stage s1) -----------------------------------------------------------------------
+    if (FULL || i + 1 < nstep) stage_out(breg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 1, skey[s1]);
+    mfma_group(0);
+    mfma_group(1);
+    // ---- loads of step i+4 into the stage just drained; restore the buffer of step i-1 for step i+2 -----------
+    if (FULL || i + 4 < nstep) prefetch(breg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 4);
+    mfma_group(2);
+    if (FULL || (i >= 1 && i + 2 < nstep)) unscatter(i - 1, skey[s2]);
+    mfma_group(3);
     __syncthreads();
-    // scatter the sparse entries of this K-step
-#pragma unroll
-    for (int i = 0; i < PF; i++) {
-      if (ekey[i] >= 0) As[(cbl * 64 + (ekey[i] & 63)) * LDK + ((ekey[i] >> 6) - k0)] = (__bf16)eval_[i];
-    }
-    for (int e = p0 + tl + 128 * PF; e < p1; e += 128) {
-      int key = g.key[e];
-      float v = g.val ? g.val[e] : 1.f;
-      As[(cbl * 64 + (key & 63)) * LDK + ((key >> 6) - k0)] = (__bf16)v;
-    }
-    __syncthreads();
-    if (k0 + 64 < kend_all) {
-      if ((((k0 + 64 - kbeg) >> 6) % PCH) == 0) {     // next step starts a new chunk of offsets (uniform)
-        load_ptrs(k0 + 64);
-        __syncthreads();
-      }
-      prefetch(k0 + 64);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        af[i] = *(const bf16x8*)&As[(wm * 64 + i * 32 + r) * LDK + kk * 16 + hq * 8];
-        bfr[i] = *(const bf16x8*)&Bs[(wn * 64 + i * 32 + r) * LDK + kk * 16 + hq * 8];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) acc[i][jj] = mfma32(af[i], bfr[jj], acc[i][jj]);
-    }
-    __syncthreads();
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  int i = 0;
+  // head: steps 0..2 (no step i-1 to restore at i = 0)
+  if (i < nstep) k_step(F_{}, S0{}, i++);
+  if (i < nstep) k_step(F_{}, S1{}, i++);
+  if (i < nstep) k_step(F_{}, S2{}, i++);
+  // hot loop: three FULL steps per trip
+  for (; i + 6 < nstep; i += 3) {
+    k_step(T_{}, S0{}, i);
+    k_step(T_{}, S1{}, i + 1);
+    k_step(T_{}, S2{}, i + 2);
+  }
+  // tail
+  for (; i < nstep; i += 3) {
+    k_step(F_{}, S0{}, i);
+    if (i + 1 < nstep) k_step(F_{}, S1{}, i + 1);
+    if (i + 2 < nstep) k_step(F_{}, S2{}, i + 2);
   }
 
   float* C = g.C + (long)split * g.ncells * g.ldc;
@@ -348,15 +441,22 @@ static int set_smem(const void* fn, size_t smem, bool* done) {
   return SCP_OK;
 }
 
+// smallest split-K factor scp_spmm_fwd_bf16 accepts for F features (its per-slab offset table holds PCH K-steps)
+extern "C" int scp_spmm_fwd_bf16_min_split(int F) {
+  int ksteps = (F + 63) / 64;
+  return (ksteps + PCH - 1) / PCH;
+}
+
 extern "C" int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
                                  const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream_) {
   SCP_CHECK(ncells > 0 && N > 0 && F > 0, SCP_ERR_ARG, "scp_spmm_fwd_bf16: sizes must be positive");
   SCP_CHECK(t_ptr && t_key && Wbf && Y, SCP_ERR_ARG, "scp_spmm_fwd_bf16: null pointer");
   SCP_CHECK(ldw % 8 == 0 && ldw >= F && ((uintptr_t)Wbf % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_fwd_bf16: shadow weights need a 16-byte aligned base and ld %% 8 == 0");
-  static bool done = false;
-  size_t smem = (size_t)(256 + 128) * LDK * sizeof(__bf16) + 4 * (PCH + 1) * sizeof(int);
-  int rc = set_smem((const void*)spmm_fwd_bf16_kernel, smem, &done);
+  static bool done_v = false, done_n = false;
+  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 4 * (PCH + 1) * sizeof(int);
+  int rc = t_val ? set_smem((const void*)spmm_fwd_bf16_kernel<true>, smem, &done_v)
+                 : set_smem((const void*)spmm_fwd_bf16_kernel<false>, smem, &done_n);
   if (rc) return rc;
   SpArgs g = {};
   g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
@@ -368,9 +468,14 @@ extern "C" int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr,
   int per = (ksteps + nsplit - 1) / nsplit;
   g.ksplit_len = per * 64;
   g.nsplit = (ksteps + per - 1) / per;
+  SCP_CHECK(per <= PCH, SCP_ERR_SHAPE,
+            "scp_spmm_fwd_bf16: %d K-steps per slab exceed %d; use nsplit >= scp_spmm_fwd_bf16_min_split(F)", per, PCH);
   int units = g.tiles_n * g.nsplit;
   int grid = 8 * g.tiles_m * ((units + 7) / 8);
-  hipLaunchKernelGGL(spmm_fwd_bf16_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+  if (t_val)
+    hipLaunchKernelGGL(spmm_fwd_bf16_kernel<true>, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+  else
+    hipLaunchKernelGGL(spmm_fwd_bf16_kernel<false>, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

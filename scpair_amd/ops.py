@@ -199,7 +199,7 @@ class FcnnLayerFn(torch.autograd.Function):
         use_bf = sparse and ns == 1 and shadow is not None
         if use_bf:
             tiles_ = ((Bn + 255) // 256) * ((H + 127) // 128)
-            nsplit = max(1, min(512 // max(tiles_, 1), ((F + 63) // 64) // 4, 16))
+            nsplit = max(1, min(512 // max(tiles_, 1), ((F + 63) // 64) // 4, 16), L.scp_spmm_fwd_bf16_min_split(F))
         else:
             nsplit = _pick_split(Bn, H, F)
         nsplit = L.scp_gemm_split_count(F, nsplit)
