@@ -91,11 +91,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus and world > 1:
         a.gpus = world
+    # rehearsal knob: SCPAIR_BENCH_BACKEND=gloo runs the N>1 path with every rank on the visible GPU(s) of a
+    # one-GPU box (RCCL refuses two ranks on one device); the driver's multi-GPU runs use nccl (= RCCL)
+    backend = os.environ.get("SCPAIR_BENCH_BACKEND", "nccl")
+    if os.environ.get("SCPAIR_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SCPAIR_BENCH_WATCHDOG"]), exit=True)
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import scpair_amd as S
     from scpair_amd import synth
     S.set_precision(a.precision)

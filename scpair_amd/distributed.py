@@ -25,6 +25,7 @@ class GradSync:
         self.world = dist.get_world_size(group)
         self.big = big
         self._pending = []
+        self._backend = dist.get_backend(group)
 
     # -- batch sharding --------------------------------------------------------------------------------------
     def shard(self, rows):
@@ -40,16 +41,26 @@ class GradSync:
     def start_all_reduce(self, grads):
         """Issue async SUM all-reduces for `grads` (list of tensors); returns nothing, call finish()."""
         small = [g for g in grads if g.numel() < self.big]
+        if self._backend != "nccl" and any(g.is_cuda for g in grads):
+            # gloo with device tensors (one-GPU rehearsal of the N>1 path only): stage through host memory; gloo's
+            # own device all-reduce stalls on this image
+            for g in grads:
+                h = g.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                g.copy_(h)
+            return
+        async_ok = True
         for g in grads:
             if g.numel() >= self.big:
-                self._pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+                self._pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_ok), None, None))
         if small:
             flat = torch.cat([g.reshape(-1) for g in small])
-            self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, small))
+            self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_ok), flat, small))
 
     def finish(self):
         for work, flat, small in self._pending:
-            work.wait()
+            if work is not None:
+                work.wait()
             if flat is not None:
                 o = 0
                 for g in small:
