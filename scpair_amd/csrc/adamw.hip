@@ -27,7 +27,61 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
   float step_size = t.lr / t.bias_corr1;
   float inv_sqrt_bc2 = 1.f / sqrtf(t.bias_corr2);
   bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
+  auto update = [&](float& p, float g, float& m, float& v) {
+    float gk = g * t.grad_scale;
+    p *= decay;
+    m = m + (gk - m) * (1.f - b1);
+    v = v * b2 + gk * gk * (1.f - b2);
+    float denom = sqrtf(v) * inv_sqrt_bc2 + pk.eps;
+    p -= step_size * (m / denom);
+  };
+  auto shadow4 = [&](long i, const float (&pa)[4]) {
+    __bf16* sh = (__bf16*)t.p_bf16;
+    if ((t.cols & 3) == 0) {
+      long rr = i / t.cols, cc = i - rr * t.cols;
+      bf16x4 o;
 #pragma unroll
+      for (int k = 0; k < 4; k++) o[k] = (__bf16)pa[k];
+      *(bf16x4*)(sh + rr * t.ld_bf16 + cc) = o;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        long rr = (i + k) / t.cols, cc = (i + k) - rr * t.cols;
+        sh[rr * t.ld_bf16 + cc] = (__bf16)pa[k];
+      }
+    }
+  };
+  if (vec && base + ADAM_CHUNK <= t.n) {
+    // interior chunk: all 16 vector loads of the thread are issued before the first store (64 B x 4 streams in
+    // flight per lane); the streams are read and written once, so they bypass the caches' retention (nontemporal)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 p[4], g[4], m[4], v[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      long i = base + (long)it * 1024 + threadIdx.x * 4;
+      p[it] = __builtin_nontemporal_load((const f4*)(t.p + i));
+      g[it] = __builtin_nontemporal_load((const f4*)(t.g + i));
+      m[it] = __builtin_nontemporal_load((const f4*)(t.m + i));
+      v[it] = __builtin_nontemporal_load((const f4*)(t.v + i));
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      long i = base + (long)it * 1024 + threadIdx.x * 4;
+      float pa[4], ma[4], va[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        pa[k] = p[it][k]; ma[k] = m[it][k]; va[k] = v[it][k];
+        update(pa[k], g[it][k], ma[k], va[k]);
+      }
+      f4 po = {pa[0], pa[1], pa[2], pa[3]}, mo = {ma[0], ma[1], ma[2], ma[3]}, vo = {va[0], va[1], va[2], va[3]};
+      __builtin_nontemporal_store(po, (f4*)(t.p + i));
+      if (t.p_bf16) shadow4(i, pa);
+      __builtin_nontemporal_store(mo, (f4*)(t.m + i));
+      __builtin_nontemporal_store(vo, (f4*)(t.v + i));
+    }
+    return;
+  }
+#pragma unroll 1
   for (int it = 0; it < 4; it++) {
     long i = base + (long)it * 1024 + threadIdx.x * 4;
     if (i >= t.n) break;
@@ -36,42 +90,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
       float pa[4] = {p.x, p.y, p.z, p.w}, ga[4] = {g.x, g.y, g.z, g.w}, ma[4] = {m.x, m.y, m.z, m.w},
             va[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        float gk = ga[k] * t.grad_scale;
-        pa[k] *= decay;
-        ma[k] = ma[k] + (gk - ma[k]) * (1.f - b1);
-        va[k] = va[k] * b2 + gk * gk * (1.f - b2);
-        float denom = sqrtf(va[k]) * inv_sqrt_bc2 + pk.eps;
-        pa[k] -= step_size * (ma[k] / denom);
-      }
+      for (int k = 0; k < 4; k++) update(pa[k], ga[k], ma[k], va[k]);
       *(float4*)(t.p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
-      if (t.p_bf16) {
-        __bf16* sh = (__bf16*)t.p_bf16;
-        if ((t.cols & 3) == 0) {
-          long rr = i / t.cols, cc = i - rr * t.cols;
-          bf16x4 o;
-#pragma unroll
-          for (int k = 0; k < 4; k++) o[k] = (__bf16)pa[k];
-          *(bf16x4*)(sh + rr * t.ld_bf16 + cc) = o;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            long rr = (i + k) / t.cols, cc = (i + k) - rr * t.cols;
-            sh[rr * t.ld_bf16 + cc] = (__bf16)pa[k];
-          }
-        }
-      }
+      if (t.p_bf16) shadow4(i, pa);
       *(float4*)(t.m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
       *(float4*)(t.v + i) = make_float4(va[0], va[1], va[2], va[3]);
     } else {
       for (int k = 0; k < 4 && i + k < t.n; k++) {
-        float gk = t.g[i + k] * t.grad_scale;
-        float p = t.p[i + k] * decay;
-        float m = t.m[i + k];
-        m = m + (gk - m) * (1.f - b1);
-        float v = t.v[i + k] * b2 + gk * gk * (1.f - b2);
-        float denom = sqrtf(v) * inv_sqrt_bc2 + pk.eps;
-        p = p - step_size * (m / denom);
+        float p = t.p[i + k], m = t.m[i + k], v = t.v[i + k];
+        update(p, t.g[i + k], m, v);
         t.p[i + k] = p;
         if (t.p_bf16) {
           long rr = (i + k) / t.cols, cc = (i + k) - rr * t.cols;
