@@ -90,3 +90,16 @@ if "small" in which:
     def fb():
         y = ops.linear(x, W, bb); y.backward(dy)
     print(f"linear 900->40 fwd+bwd   : {timeit(fb):8.1f} us")
+
+if "decdbg" in which:
+    import ctypes
+    out = (ctypes.c_longlong * 96)()
+    L.scp_dec_dbg_read.restype = ctypes.c_int
+    L.scp_dec_dbg_read(out)
+    v = list(out)
+    names = ["top_sync", "stage+zero+sync", "scatter", "issue+sync", "Zmfma", "epilogue+dzstore", "sync", "gradmfma"]
+    for mode, nm in enumerate(["BER_TRAIN", "BER_EVAL", "NB_STATS", "NB_LOSS", "NB_GRAD"]):
+        n = v[mode * 16 + 8]
+        if n:
+            print(nm, "iters", n, "total", v[mode * 16 + 9], {names[k]: round(v[mode * 16 + k] / n) for k in range(8)},
+                  "sum/iter", round(sum(v[mode * 16:mode * 16 + 8]) / n), "total/iter", round(v[mode * 16 + 9] / n))

@@ -64,23 +64,48 @@ template <bool FAST> __device__ __forceinline__ float div_(float a, float b) { r
 template <bool FAST> __device__ __forceinline__ float sigm_(float x) { return div_<FAST>(1.f, 1.f + exp_<FAST>(-x)); }
 
 // lgamma(y+th) - lgamma(th) - lgamma(y+1) and digamma(y+th) - digamma(th).  For small integer counts the exact
-// identities  sum_{i<y} log((th+i)/(i+1))  and  sum_{i<y} 1/(th+i)  avoid both the slow lgammaf/digamma
-// evaluations and the cancellation of lgamma(y+th)-lgamma(th) at large theta.
+// identities  sum_{i<y} log((th+i)/(i+1))  and  sum_{i<y} 1/(th+i)  avoid both the slow lgammaf/digamma evaluations
+// and the cancellation of lgamma(y+th)-lgamma(th) at large theta.  The sums are evaluated without a transcendental
+// per term: the log of a running product (one log at the end; the product of <= 12 factors <= 1035 fits fp32) and
+// a running fraction N/D (one division at the end).  For th > 1024 the factors are expanded around th instead
+// (i/th < 0.011: three series terms leave < 4e-9 per factor).
 template <bool FAST>
 __device__ __forceinline__ float lgam3(float y, float th) {
   if (y <= 12.f && y == floorf(y)) {
-    float s = 0.f;
-    for (float i = 0.f; i < y; i += 1.f) s += log_<FAST>(div_<FAST>(th + i, i + 1.f));
-    return s;
+    float den = 1.f;
+    if (th > 1024.f) {
+      for (float i = 1.f; i < y; i += 1.f) den *= i + 1.f;
+      float it = div_<FAST>(1.f, th);
+      float s1 = 0.5f * y * (y - 1.f);                          // sum i
+      float s2 = (y - 1.f) * y * (2.f * y - 1.f) * (1.f / 6.f);  // sum i^2
+      float s3 = s1 * s1;                                       // sum i^3
+      return y * log_<FAST>(th) + it * (s1 - it * (0.5f * s2 - it * (1.f / 3.f) * s3)) - log_<FAST>(den);
+    }
+    float num = 1.f;
+    for (float i = 0.f; i < y; i += 1.f) {
+      num *= th + i;
+      den *= i + 1.f;
+    }
+    return log_<FAST>(div_<FAST>(num, den));
   }
   return lgammaf(y + th) - lgammaf(th) - lgammaf(y + 1.f);
 }
 template <bool FAST>
 __device__ __forceinline__ float digam2(float y, float th) {
   if (y <= 12.f && y == floorf(y)) {
-    float s = 0.f;
-    for (float i = 0.f; i < y; i += 1.f) s += div_<FAST>(1.f, th + i);
-    return s;
+    if (th > 1024.f) {
+      float it = div_<FAST>(1.f, th);
+      float s1 = 0.5f * y * (y - 1.f);
+      float s2 = (y - 1.f) * y * (2.f * y - 1.f) * (1.f / 6.f);
+      return it * (y - it * (s1 - it * s2));
+    }
+    float n = 0.f, d = 1.f;
+    for (float i = 0.f; i < y; i += 1.f) {
+      float x = th + i;
+      n = n * x + d;
+      d *= x;
+    }
+    return div_<FAST>(n, d);
   }
   return digammaf_pos(y + th) - digammaf_pos(th);
 }
@@ -506,40 +531,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       }
     }
     if (MODE == MODE_BER_TRAIN || MODE == MODE_NB_LOSS || MODE == MODE_NB_STATS) {
-      // combine the 32 lanes of each half, then the two waves sharing a cell half
+      // Row reductions over the 64 feature columns of the chunk's tiles: the per-lane partials go through an LDS
+      // tile rt[cell][65] (odd stride: conflict-free both ways; it reuses the dZ images, idle here) and are summed
+      // by 4 threads per cell in a fixed order.
+      float* rt = (float*)dzA;
+      const int rrow = tid >> 2, rq = tid & 3;
+      auto row_sum = [&]() {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) a += rt[rrow * 65 + rq * 16 + j];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        return a;
+      };
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        float v0 = racc0[e], v1 = racc1[e];
-        if (MODE == MODE_NB_STATS) {
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            float m2 = __shfl_xor(v0, o, 64), s2 = __shfl_xor(v1, o, 64);
-            float mn = fmaxf(v0, m2);
-            float e1 = (v0 == -INFINITY) ? 0.f : expf(v0 - mn), e2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
-            v1 = v1 * e1 + s2 * e2;
-            v0 = mn;
-          }
-        } else {
-          v0 = half_sum(v0);
-        }
-        if (r == 0) {
-          int cl = ti * 32 + acc_row(e, lane);
-          rred[(tj * 2 + 0) * CB + cl] = v0;
-          rred[(tj * 2 + 1) * CB + cl] = v1;
-        }
-      }
+      for (int e = 0; e < 16; e++) rt[(ti * 32 + acc_row(e, lane)) * 65 + tj * 32 + r] = racc0[e];
       __syncthreads();
-      if (tid < CB && c0 + tid < g.B) {
-        float a0 = rred[0 * CB + tid], a1 = rred[1 * CB + tid], b0 = rred[2 * CB + tid], b1 = rred[3 * CB + tid];
-        float* dst = g.row_slab + ((long)blockIdx.x * g.B + c0 + tid) * 2;
-        if (MODE == MODE_NB_STATS) {
-          float mn = fmaxf(a0, b0);
-          float e1 = (a0 == -INFINITY) ? 0.f : expf(a0 - mn), e2 = (b0 == -INFINITY) ? 0.f : expf(b0 - mn);
-          dst[0] = mn;
-          dst[1] = a1 * e1 + b1 * e2;
-        } else {
-          dst[0] = a0 + b0;
+      float* dst = g.row_slab + ((long)blockIdx.x * g.B + c0 + rrow) * 2;
+      const bool wr = (rq == 0) && (c0 + rrow < g.B);
+      if (MODE == MODE_NB_STATS) {
+        // log-sum-exp pieces (m, s) per lane -> row maximum first, then the sums rescaled to it
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; j++) m = fmaxf(m, rt[rrow * 65 + rq * 16 + j]);
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        if (rq == 0) rred[rrow] = m;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int cl = ti * 32 + acc_row(e, lane);
+          float sc = (racc0[e] == -INFINITY) ? 0.f : racc1[e] * expf(racc0[e] - rred[cl]);
+          rt[cl * 65 + tj * 32 + r] = sc;
+        }
+        __syncthreads();
+        float ssum = row_sum();
+        if (wr) {
+          dst[0] = m;
+          dst[1] = ssum;
+        }
+      } else {
+        float ssum = row_sum();
+        if (wr) {
+          dst[0] = ssum;
           dst[1] = 0.f;
         }
       }
