@@ -268,12 +268,20 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
 
 // ------------------------------------------------------------------------------------------------------
 // wgrad: tile 128 hidden x 256 features x 64 cells (one cell block per K-step), 8 waves as 2 (hidden) x 4 (features)
+//
+// Same pipeline as the forward kernel with the operand roles swapped: the sparse X tile [feature][cell] lives in
+// three LDS buffers (scatter for step i+1, MFMAs of step i, un-scatter of step i-1), the dense dY^T tile in two,
+// one barrier per step, three steps of loads in flight in registers.
 // ------------------------------------------------------------------------------------------------------
+template <bool HASVAL>
 __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
+  constexpr int EPT = HASVAL ? 4 : 2;             // sparse entries held per thread and stage
+  constexpr int ASZ = 128 * LDK, BSZ = 256 * LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* As = (__bf16*)smem_raw;        // [128][LDK]   dYT tile  [hidden][cell]
-  __bf16* Bs = As + 128 * LDK;           // [256][LDK]   X tile    [feature][cell]
-  int* ptrs = (int*)(Bs + 256 * LDK);    // [2][PCH + 1]: entry range [start, end) of this feature tile per cell block
+  __bf16* Bs = (__bf16*)smem_raw;        // [3][256][LDK]   X tile    [feature][cell]
+  __bf16* As = Bs + 3 * BSZ;             // [2][128][LDK]   dYT tile  [hidden][cell]
+  int* ptrs = (int*)(As + 2 * ASZ);      // [2][PCH + 1]: entry range [start, end) of this feature tile per cell block
+  __shared__ int ovf[3];                 // step+1 of a step whose X buffer holds entries beyond the per-thread slots
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, hq = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
   if (unit >= g.tiles_n) return;
   const int m0 = m_tile * 128, n0 = unit * 256;
   const int nend = min(n0 + 256, g.F);
+  const int nstep = g.ncb;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -294,95 +303,162 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][jj][e] = 0.f;
 
-  uint4 areg[2];
-  int ekey[PF];
-  float eval_[PF];
-  int p0 = 0, p1 = 0;
+  u32x4 areg[3][2];
+  uint32_t ekey[3][EPT], eval_[3][HASVAL ? EPT : 1];
+  int p0[3], p1[3];
+  int skey[3][EPT];                               // LDS offsets this thread scattered for step j (slot j%3), -1 = none
+  const int arow = tid >> 3, akc = tid & 7;       // dYT tile chunk of this thread (and +64 rows for the second one)
 
-  auto prefetch = [&](int cb) {
-    int k0 = cb * 64;
+  auto prefetch = [&](u32x4 (&ar)[2], uint32_t (&ek)[EPT], uint32_t (&ev)[HASVAL ? EPT : 1], int& q0, int& q1,
+                      int step) {
+    const int k0 = step * 64;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      int c = tid + 512 * i;
-      int row = c >> 3, kc = c & 7;
-      int m = m0 + row, k = k0 + kc * 8;
-      areg[i] = ld16(g.D + (long)m * g.ldd + k, m < g.N && k < g.ldd);
+      int m = min(m0 + arow + 64 * i, g.N - 1);
+      long k = min((long)k0 + akc * 8, g.ldd - 8);
+      ar[i] = *(const u32x4*)(g.D + (long)m * g.ldd + k);
     }
-    p0 = ptrs[cb % (PCH + 1)];
-    p1 = ptrs[(PCH + 1) + cb % (PCH + 1)];
+    q0 = ptrs[step];
+    q1 = ptrs[(PCH + 1) + step];
+    const int elast = max(q1 - 1, 0);
 #pragma unroll
-    for (int i = 0; i < PF; i++) {
-      int e = p0 + tid + 512 * i;
-      ekey[i] = (e < p1) ? g.key[e] : -1;
-      eval_[i] = (e < p1 && g.val) ? g.val[e] : 1.f;
+    for (int i = 0; i < EPT; i++) {
+      int e = min(q0 + tid + 512 * i, elast);
+      ek[i] = (uint32_t)g.key[e];
+      if constexpr (HASVAL) ev[i] = __float_as_uint(g.val[e]);
+    }
+  };
+  // registers of one stage -> LDS operands of `step`
+  auto stage_out = [&](const u32x4 (&ar)[2], const uint32_t (&ek)[EPT], const uint32_t (&ev)[HASVAL ? EPT : 1], int q0,
+                       int q1, int step, int (&sk)[EPT]) {
+    const int k0 = step * 64;
+    __bf16* Ad = As + (step & 1) * ASZ;
+    __bf16* Bd = Bs + (step % 3) * BSZ;
+    const bool kin = (long)k0 + akc * 8 < g.ldd;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      u32x4 v = ar[i];
+      if (!(kin && m0 + arow + 64 * i < g.N)) v = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)&Ad[(arow + 64 * i) * LDK + akc * 8] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      sk[i] = -1;
+      if (q0 + tid + 512 * i < q1) {
+        int key = (int)ek[i];
+        float v = 1.f;
+        if constexpr (HASVAL) v = __uint_as_float(ev[i]);
+        int off = ((key >> 6) - n0) * LDK + (key & 63);
+        Bd[off] = (__bf16)v;
+        sk[i] = off;
+      }
+    }
+    if (q0 + 512 * EPT < q1) {                    // overflow of a dense (cell block, feature tile): rare, uniform
+      if (tid == 0) ovf[step % 3] = step + 1;
+      for (int e = q0 + tid + 512 * EPT; e < q1; e += 512) {
+        int key = (int)gload_b32_sync(g.key + e);
+        float v = 1.f;
+        if constexpr (HASVAL) v = __uint_as_float(gload_b32_sync(g.val + e));
+        Bd[((key >> 6) - n0) * LDK + (key & 63)] = (__bf16)v;
+      }
+    }
+  };
+  auto zero_B = [&](int buf) {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4* q = (u32x4*)(Bs + buf * BSZ);
+    for (int i = tid; i < BSZ * 2 / 16; i += 512) q[i] = z;
+  };
+  // undo the scatter of `step` (whose MFMAs are done): its buffer is all zero again afterwards
+  auto unscatter = [&](int step, const int (&sk)[EPT]) {
+    __bf16* Bd = Bs + (step % 3) * BSZ;
+    // the tag was written two barriers ago (when the step was staged) and the slot is next written one barrier
+    // from now, so every thread reads the same value; a stale tag of step-3 never matches
+    if (ovf[step % 3] == step + 1) {
+      zero_B(step % 3);
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPT; i++)
+        if (sk[i] >= 0) Bd[sk[i]] = (__bf16)0.f;
     }
   };
 
-  auto load_ptrs = [&](int cbfirst) {
-    for (int i = tid; i < 2 * (PCH + 1); i += 512) {
-      int which = i / (PCH + 1), cbx = cbfirst + i % (PCH + 1);
-      ptrs[i] = (cbx < g.ncb) ? g.ptr[(long)cbx * g.F + (which ? nend : n0)] : 0;
-    }
-  };
-  load_ptrs(0);
+  // entry ranges of this feature tile in every cell block (ncb <= PCH + 1, checked by the host)
+  for (int i = tid; i < 2 * (PCH + 1); i += 512) {
+    int which = i / (PCH + 1), cbx = i % (PCH + 1);
+    ptrs[i] = (cbx < g.ncb) ? g.ptr[(long)cbx * g.F + (which ? nend : n0)] : 0;
+  }
+  zero_B(0);
+  zero_B(1);
+  zero_B(2);
+  if (tid < 3) ovf[tid] = 0;
   __syncthreads();
-  prefetch(0);
-  for (int cb = 0; cb < g.ncb; cb++) {
-    {
-      uint4 z = {0u, 0u, 0u, 0u};
-      uint4* q = (uint4*)Bs;
-      for (int i = tid; i < 256 * LDK * 2 / 16; i += 512) q[i] = z;
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        int c = tid + 512 * i;
-        int row = c >> 3, kc = c & 7;
-        *(uint4*)&As[row * LDK + kc * 8] = areg[i];
+  for (int s = 0; s < 3; s++)
+    if (s < nstep) prefetch(areg[s], ekey[s], eval_[s], p0[s], p1[s], s);
+  stage_out(areg[0], ekey[0], eval_[0], p0[0], p1[0], 0, skey[0]);
+  if (3 < nstep) prefetch(areg[0], ekey[0], eval_[0], p0[0], p1[0], 3);
+  __syncthreads();
+
+  // One K-step; FULL = steps i-1 .. i+4 all exist (straight-line body, see the forward kernel)
+  auto k_step = [&](auto full_c, auto s_c, int i) {
+    constexpr bool FULL = decltype(full_c)::value;
+    constexpr int s = decltype(s_c)::value;       // i % 3
+    constexpr int s1 = (s + 1) % 3, s2 = (s + 2) % 3;
+    const __bf16* Ar = As + (i & 1) * ASZ;
+    const __bf16* Br = Bs + s * BSZ;
+    bf16x8 af[4][2], bfr[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        af[kk][q] = *(const bf16x8*)&Ar[(wm * 64 + q * 32 + r) * LDK + kk * 16 + hq * 8];
+        bfr[kk][q] = *(const bf16x8*)&Br[(wn * 64 + q * 32 + r) * LDK + kk * 16 + hq * 8];
       }
-    }
+    auto mfma_group = [&](int kk) {
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) acc[q][jj] = mfma32(af[kk][q], bfr[kk][jj], acc[q][jj]);
+    };
+    if (FULL || i + 1 < nstep) stage_out(areg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 1, skey[s1]);
+    mfma_group(0);
+    mfma_group(1);
+    if (FULL || i + 4 < nstep) prefetch(areg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 4);
+    mfma_group(2);
+    if (FULL || (i >= 1 && i + 2 < nstep)) unscatter(i - 1, skey[s2]);
+    mfma_group(3);
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PF; i++) {
-      if (ekey[i] >= 0) Bs[((ekey[i] >> 6) - n0) * LDK + (ekey[i] & 63)] = (__bf16)eval_[i];
-    }
-    for (int e = p0 + tid + 512 * PF; e < p1; e += 512) {
-      int key = g.key[e];
-      float v = g.val ? g.val[e] : 1.f;
-      Bs[((key >> 6) - n0) * LDK + (key & 63)] = (__bf16)v;
-    }
-    __syncthreads();
-    if (cb + 1 < g.ncb) {
-      if (((cb + 1) % (PCH + 1)) == 0) {
-        load_ptrs(cb + 1);
-        __syncthreads();
-      }
-      prefetch(cb + 1);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      bf16x8 af[2], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        af[i] = *(const bf16x8*)&As[(wm * 64 + i * 32 + r) * LDK + kk * 16 + hq * 8];
-        bfr[i] = *(const bf16x8*)&Bs[(wn * 64 + i * 32 + r) * LDK + kk * 16 + hq * 8];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int jj = 0; jj < 2; jj++) acc[i][jj] = mfma32(af[i], bfr[jj], acc[i][jj]);
-    }
-    __syncthreads();
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  int i = 0;
+  if (i < nstep) k_step(F_{}, S0{}, i++);
+  if (i < nstep) k_step(F_{}, S1{}, i++);
+  if (i < nstep) k_step(F_{}, S2{}, i++);
+  for (; i + 6 < nstep; i += 3) {
+    k_step(T_{}, S0{}, i);
+    k_step(T_{}, S1{}, i + 1);
+    k_step(T_{}, S2{}, i + 2);
+  }
+  for (; i < nstep; i += 3) {
+    k_step(F_{}, S0{}, i);
+    if (i + 1 < nstep) k_step(F_{}, S1{}, i + 1);
+    if (i + 2 < nstep) k_step(F_{}, S2{}, i + 2);
   }
 
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i2 = 0; i2 < 2; i2++)
 #pragma unroll
     for (int jj = 0; jj < 2; jj++) {
       int n = n0 + wn * 64 + jj * 32 + r;
       if (n >= g.F) continue;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        int m = m0 + wm * 64 + i * 32 + acc_row(e, lane);
-        if (m < g.N) g.C[(long)m * g.ldc + n] = acc[i][jj][e];
+        int m = m0 + wm * 64 + i2 * 32 + acc_row(e, lane);
+        if (m < g.N) g.C[(long)m * g.ldc + n] = acc[i2][jj][e];
       }
     }
 }
@@ -486,16 +562,22 @@ extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, 
   SCP_CHECK(t_ptr && t_key && dYT && dW, SCP_ERR_ARG, "scp_spmm_dw_bf16: null pointer");
   SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_dw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
-  static bool done = false;
-  size_t smem = (size_t)(256 + 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
-  int rc = set_smem((const void*)spmm_dw_bf16_kernel, smem, &done);
+  SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16: more than %d cells per call unsupported",
+            64 * (PCH + 1));
+  static bool done_v = false, done_n = false;
+  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
+  int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true>, smem, &done_v)
+                 : set_smem((const void*)spmm_dw_bf16_kernel<false>, smem, &done_n);
   if (rc) return rc;
   SpArgs g = {};
   g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
   g.D = (const __bf16*)dYT; g.ldd = ldt; g.C = dW; g.ldc = ldw;
   g.tiles_m = (N + 127) / 128; g.tiles_n = (F + 255) / 256; g.nsplit = 1;
   int grid = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
-  hipLaunchKernelGGL(spmm_dw_bf16_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+  if (t_val)
+    hipLaunchKernelGGL(spmm_dw_bf16_kernel<true>, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+  else
+    hipLaunchKernelGGL(spmm_dw_bf16_kernel<false>, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
