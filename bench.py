@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--cpu-steps", type=int, default=3, help="paired steps of the CPU baseline (0 = skip)")
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--zinb", action="store_true", help="C3: zero-inflated NB for RNA (the G x G dropout layer is live)")
     return ap.parse_args()
 
 
@@ -59,7 +60,7 @@ class Direction:
             self.dec = S.Output_Module_Ber(output_dim=out_dim, output_batch_num=0, hidden_layer=hidden,
                                            infer_library_size=infer_lib, sample_factor=sample_factor, feature_factor=False)
         else:
-            self.dec = _raw_decoder(S, out_dim, hidden, sample_factor)
+            self.dec = _raw_decoder(S, out_dim, hidden, sample_factor, zinb=(out_dist == "zinb"))
         self.enc.apply(S.init_weights).to(dev)
         self.dec.apply(S.init_weights).to(dev)
         de, ne, _, _ = S.add_weight_decay(self.enc, output_layer=["output"])
@@ -75,12 +76,12 @@ class Direction:
         return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None)
 
 
-def _raw_decoder(S, out_dim, hidden, sample_factor):
+def _raw_decoder(S, out_dim, hidden, sample_factor, zinb=False):
     # zero_inflated=False ('nb' headline config).  The reference also allocates an unused Linear(G,G)
     # `output_inverse_dispersion` (model.py:224-225, 1.6 GB at G=20k, never touched by forward/backward); it is kept
     # so the state_dict stays interchangeable.
     return S.Output_Module_Raw(output_dim=out_dim, output_batch_num=0, hidden_layer=hidden, infer_library_size=not sample_factor,
-                               sample_factor=sample_factor, feature_factor=False, zero_inflated=False,
+                               sample_factor=sample_factor, feature_factor=False, zero_inflated=zinb,
                                dispersion="feature-cell")
 
 
@@ -120,7 +121,7 @@ def main():
 
     # ---- the two predictors (reference defaults: model.py:365-372) ---------------------------------------------
     A = Direction(S, a.genes, a.peaks, a.hidden, "ber", infer_lib=True, sample_factor=False, dropout=a.dropout, dev=dev)
-    Bd = Direction(S, a.peaks, a.genes, a.hidden, "nb", infer_lib=False, sample_factor=True, dropout=a.dropout, dev=dev)
+    Bd = Direction(S, a.peaks, a.genes, a.hidden, "zinb" if a.zinb else "nb", infer_lib=False, sample_factor=True, dropout=a.dropout, dev=dev)
     sync = None
     if world > 1:
         from scpair_amd.distributed import GradSync

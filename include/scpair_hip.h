@@ -31,6 +31,10 @@ int scp_tiles_build(const int64_t* indptr, const int32_t* indices, const float* 
                     const int64_t* rows, int B, int F, int32_t* ptr, int32_t* key, float* val /* nullable */,
                     float* lib /* [B] row sums, nullable */, int32_t* nnan /* [1], nullable */, int32_t* ws,
                     void* stream);
+/* tile list -> dense [B][ld] fp32 labels (zeros elsewhere) for the likelihoods evaluated on materialised tensors
+ * (ZINB, Gaussian: loss.py:22-27, 46-51); replaces the dense gather of model.py:26-38 */
+int scp_tiles_to_dense(int B, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val, float* out, long ld,
+                       void* stream);
 
 /* ---- first encoder layer on sparse counts: nn.Linear(F_in, H) of FCNN (utils.py:57) applied to
  *      the dense x in Input_Module (model.py:128-130, 136-140), forward and weight gradient ---- */
@@ -58,6 +62,11 @@ int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32
 int scp_gemm_nt(int M, int N, int K, const float* A, long a_row_stride, long a_k_stride, const float* B,
                 long b_row_stride, long b_k_stride, float* C, long ldc, const float* bias /* [N] nullable */,
                 int accumulate, int nsplit, int ns, void* stream);
+/* wide plain GEMMs (ZINB G x G layer model.py:228, VAE 900<->G layers pairedVAE.py:111-119) in bf16 mode: rocBLAS,
+ * bf16 operands, fp32 accumulate/output.  Column-major BLAS convention, ta/tb: 0 = N, 1 = T; see libgemm.hip for the
+ * three row-major nn.Linear cases */
+int scp_gemm_lib_bf16(int ta, int tb, int m, int n, int k, const void* A_bf16, long lda, const void* B_bf16, long ldb,
+                      float* C, long ldc, void* stream);
 int scp_slab_reduce(const float* slabs, long slab_stride, int nslab, int rows, int cols, long ld,
                     const float* bias, float* out, long ldo, void* stream);
 int scp_colsum(const float* X, long ld, int rows, int cols, float* out, float* partials_ws /* [32*cols] */,

@@ -34,6 +34,7 @@ _SIGS = {
     "scp_version": (I, []),
     "scp_tiles_ptr_len": (L, [I, I]),
     "scp_tiles_ws_len": (L, [I, I]),
+    "scp_tiles_to_dense": (I, [I, I, P, P, P, P, L, P]),
     "scp_tiles_build": (I, [P, P, P, P, I, I, P, P, P, P, P, P, P]),
     "scp_gemm_split_count": (I, [I, I]),
     "scp_spmm_fwd": (I, [I, I, I, P, P, P, P, L, P, L, P, I, I, P]),
@@ -44,6 +45,7 @@ _SIGS = {
     "scp_spmm_fwd_bf16": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
     "scp_spmm_dw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
     "scp_gemm_nt": (I, [I, I, I, P, L, L, P, L, L, P, L, P, I, I, I, P]),
+    "scp_gemm_lib_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P]),
     "scp_slab_reduce": (I, [P, L, I, I, I, L, P, P, L, P]),
     "scp_colsum": (I, [P, L, I, I, P, P, P]),
     "scp_ln_act_fwd": (I, [P, L, L, I, P, P, P, I, I, F, F, F, U64, P, L, P, P, L, P]),

@@ -9,12 +9,12 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wno-u
 OBJ="$HERE/build"
 mkdir -p "$OBJ"
 pids=()
-for f in capi gemm spmm_bf16 tiles norm_act adamw elementwise decoder decoder_ber_ns1 decoder_ber_ns3 decoder_nb_ns1 decoder_nb_ns3; do
+for f in capi gemm libgemm spmm_bf16 tiles norm_act adamw elementwise decoder decoder_ber_ns1 decoder_ber_ns3 decoder_nb_ns1 decoder_nb_ns3; do
   if [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/decoder_kernel.h" -nt "$OBJ/$f.o" ] || [ "$ROOT/include/scpair_hip.h" -nt "$OBJ/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/*.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/*.o -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT"

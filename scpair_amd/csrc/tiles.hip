@@ -274,3 +274,28 @@ extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, co
   }
   return SCP_OK;
 }
+
+// ---- tile list -> dense [B][ld] fp32 (labels of the likelihoods that need the materialised form: ZINB, Gaussian) ----
+__global__ __launch_bounds__(256) void tiles_dense_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ key,
+                                                          const float* __restrict__ val, int B, int F,
+                                                          float* __restrict__ out, long ld) {
+  // one workgroup per (64-cell block, slice of the block's entry range)
+  int cb = blockIdx.y;
+  int e0 = ptr[(long)cb * F], e1 = ptr[(long)(cb + 1) * F];
+  for (int e = e0 + blockIdx.x * 256 + threadIdx.x; e < e1; e += gridDim.x * 256) {
+    int k = key[e];
+    int c = cb * 64 + (k & 63);
+    if (c < B) out[(long)c * ld + (k >> 6)] = val ? val[e] : 1.f;
+  }
+}
+
+extern "C" int scp_tiles_to_dense(int B, int F, const int32_t* ptr, const int32_t* key, const float* val, float* out,
+                                  long ld, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SCP_CHECK(B > 0 && F > 0 && ptr && key && out && ld >= F, SCP_ERR_ARG, "scp_tiles_to_dense: bad argument");
+  SCP_HIP(hipMemset2DAsync(out, (size_t)ld * sizeof(float), 0, (size_t)F * sizeof(float), (size_t)B, stream));
+  int ncb = (B + 63) / 64;
+  hipLaunchKernelGGL(tiles_dense_kernel, dim3(64, ncb), dim3(256), 0, stream, ptr, key, val, B, F, out, ld);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}

@@ -138,6 +138,23 @@ def _pick_split(M, N, K):
 # ------------------------------------------------------------------------------------------------
 # Linear (dense):  y = x W^T + b
 # ------------------------------------------------------------------------------------------------
+_LIB_GEMM_MIN = 1 << 30      # M*N*K from which a plain nn.Linear goes to the library bf16 GEMM (precision 'bf16' only)
+
+
+def cast_bf16(x, rows, cols):
+    """bf16 copy [rows, ld] (ld = cols rounded up to 8, zero padded) of a contiguous fp32 [rows, cols] tensor."""
+    ld = (cols + 7) // 8 * 8
+    out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().scp_cast_bf16(x.data_ptr(), rows, cols, cols, out.data_ptr(), ld, _lib.stream()),
+               "scp_cast_bf16")
+    return out
+
+
+def gemm_lib(ta, tb, m, n, k, A, lda, B, ldb, C, ldc):
+    _lib.check(_lib.lib().scp_gemm_lib_bf16(ta, tb, m, n, k, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc,
+                                            _lib.stream()), "scp_gemm_lib_bf16")
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b):
@@ -147,18 +164,43 @@ class LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = Wc.shape[0]
         y = _empty((M, N), x)
+        ctx.has_bias = b is not None
+        ctx.lib = _ns() == 1 and M * N * K >= _LIB_GEMM_MIN and W.is_contiguous() and W.dtype == torch.float32
+        if ctx.lib:
+            # wide plain GEMM: bf16 weight shadow (kept current by FusedAdamW) x bf16 activations, library kernel
+            sh = shadow_of(W)
+            xb = cast_bf16(x, M, K)
+            gemm_lib(1, 0, N, M, K, sh, sh.shape[1], xb, xb.shape[1], y, N)
+            if b is not None:
+                slab_reduce(y, 1, M, N, y, _f32c(b))
+            ctx.save_for_backward(xb, W)
+            ctx.dims = (M, N, K)
+            return y
         gemm_nt_auto(M, N, K, x, K, 1, Wc, K, 1, y, bias=_f32c(b))
         ctx.save_for_backward(x, Wc)
-        ctx.has_bias = b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
         dy = _f32c(dy)
+        dx = dW = db = None
+        if ctx.lib:
+            xb, W = ctx.saved_tensors
+            M, N, K = ctx.dims
+            dyb = cast_bf16(dy, M, N)
+            if ctx.needs_input_grad[0]:
+                sh = shadow_of(W)
+                dx = _empty((M, K), dy)
+                gemm_lib(0, 0, K, M, N, sh, sh.shape[1], dyb, dyb.shape[1], dx, K)
+            if ctx.needs_input_grad[1]:
+                dW = _empty((N, K), dy)
+                gemm_lib(0, 1, K, N, M, xb, xb.shape[1], dyb, dyb.shape[1], dW, K)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dy, M, N)
+            return dx, dW, db
+        x, W = ctx.saved_tensors
         M, K = x.shape
         N = W.shape[0]
-        dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = _empty((M, K), x)
             # dx[m][j] = sum_n dy[m][n] W[n][j]

@@ -145,13 +145,9 @@ class BatchTiles:
         return (self.B, self.F)
 
     def to_dense(self):
-        """Dense [B, F] fp32 tensor on the device (tests / tiny inference only)."""
-        ptr = self.ptr.cpu().numpy().astype(np.int64)
-        key = self.key.cpu().numpy()[: self.nnz]
-        val = np.ones(self.nnz, np.float32) if self.val is None else self.val.cpu().numpy()[: self.nnz]
-        ncb = (self.B + 63) // 64
-        out = np.zeros((self.B, self.F), np.float32)
-        starts = ptr[: ncb * self.F + 1]
-        cb_of = np.searchsorted(starts[:: self.F][1:], np.arange(self.nnz), side="right")
-        out[cb_of * 64 + (key & 63), key >> 6] = val
-        return torch.from_numpy(out).to(self.ptr.device)
+        """Dense [B, F] fp32 tensor on the device (labels of the ZINB / Gaussian likelihoods, tiny inference)."""
+        out = torch.empty((self.B, self.F), dtype=torch.float32, device=self.ptr.device)
+        _lib.check(_lib.lib().scp_tiles_to_dense(self.B, self.F, _lib.ptr(self.ptr), _lib.ptr(self.key),
+                                                 _lib.ptr(self.val), _lib.ptr(out), self.F, _lib.stream()),
+                   "scp_tiles_to_dense")
+        return out

@@ -385,3 +385,38 @@ def test_bf16_shadow_tracks_weights(S):
     ref = torch.nn.functional.leaky_relu(tiles.to_dense().bfloat16().double() @ W.detach().bfloat16().double().t() + b.detach().double(), 0.01)
     close(out, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
     S.ops.set_precision("fp32")
+
+
+def test_linear_library_gemm_bf16(S):
+    """Wide plain nn.Linear in bf16 mode (M*N*K >= 2^30: ZINB G x G layer, VAE 900<->G layers) runs on the library
+    bf16 GEMM behind scp_gemm_lib_bf16: forward, dgrad, wgrad and bias gradient against fp64 matmuls of the
+    bf16-rounded operands; the shadow stays equal to bf16(W) across a FusedAdamW step."""
+    S.ops.set_precision("bf16")
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 2050, 1801                      # not multiples of 8: padded leading dimensions
+    assert M * N * K >= S.ops._LIB_GEMM_MIN
+    x = torch.randn(M, K, generator=g).to(S.dev).requires_grad_(True)
+    W = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.05).to(S.dev))
+    b = torch.nn.Parameter(torch.randn(N, generator=g).to(S.dev))
+    dy = torch.randn(M, N, generator=g).to(S.dev)
+    y = S.ops.linear(x, W, b)
+    y.backward(dy)
+    xb, Wb, dyb = x.detach().bfloat16().double(), W.detach().bfloat16().double(), dy.bfloat16().double()
+    sc = lambda t: 1e-4 * float(t.abs().max())
+    close(y, xb @ Wb.t() + b.detach().double(), rtol=1e-4, atol=sc(y), what="lib gemm fwd")
+    close(x.grad, dyb @ Wb, rtol=1e-4, atol=sc(x.grad), what="lib gemm dgrad")
+    close(W.grad, dyb.t() @ xb, rtol=1e-4, atol=sc(W.grad), what="lib gemm wgrad")
+    close(b.grad, dy.double().sum(0), rtol=1e-5, atol=1e-4, what="lib gemm dbias")
+    opt = S.ops.FusedAdamW([W, b], lr=1e-2, weight_decay=0.0)
+    opt.step()
+    sh = S.ops.shadow_of(W, create=False)
+    assert sh is not None and torch.equal(sh[:, :K], W.detach().bfloat16())
+    S.ops.set_precision("fp32")
+
+
+def test_tiles_to_dense(S):
+    rng = np.random.default_rng(11)
+    m = rand_csr(rng, 200, 517, 0.07)
+    rows = rng.permutation(200)[:130]
+    t = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(m, S.dev), rows)
+    np.testing.assert_array_equal(t.to_dense().cpu().numpy(), np.asarray(m[rows].todense(), dtype=np.float32))
