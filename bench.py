@@ -193,6 +193,16 @@ def main():
     tot_bytes = sum(28.0 * n for _, _, n in adam_ev)
     adam_gbs = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     n_params = A.n_trained_params() + Bd.n_trained_params()
+    # HBM bytes of the same kernel from PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes
+    # over this command; profiles/r01_adamw_traffic.json).  Only quoted when it was collected for this exact workload.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_adamw_traffic.json")) as fh:
+            tr = json.load(fh)
+        if abs(tr["algorithmic_bytes_per_step"] - 28.0 * n_params) < 1.0 and a.precision == "bf16":
+            traffic = tr["hbm_bytes_per_step"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     out = {
         "metric": "training cells/sec (whole node) paired RNA+ATAC",
@@ -209,7 +219,7 @@ def main():
                    "nnz_per_cell_atac": round(nnz_a, 1), "precision": a.precision, "parallelism": f"dp{world}",
                    "trained_params": n_params, "final_losses": losses},
         "roofline": {"kernel": "adamw_kernel (fused multi-tensor AdamW)", "bound": "hbm", "achieved": adam_gbs,
-                     "peak": 8000.0, "unit": "GB/s", "frac": adam_gbs / 8000.0, "traffic": None,
+                     "peak": 8000.0, "unit": "GB/s", "frac": adam_gbs / 8000.0, "traffic": traffic,
                      "algorithmic_bytes_per_launch_set": 28.0 * n_params,
                      "avg_ms_per_step_in_kernel": tot_ms / max(a.steps, 1)},
     }
