@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--cpu-steps", type=int, default=3, help="paired steps of the CPU baseline (0 = skip)")
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="2: the two directions (independent trainings, model.py:608) run on two HIP streams")
     ap.add_argument("--zinb", action="store_true", help="C3: zero-inflated NB for RNA (the G x G dropout layer is live)")
     return ap.parse_args()
 
@@ -163,11 +165,29 @@ def main():
         state["cur"] += a.batch
         t_rna = S.BatchTiles(rna, rows, want_lib=True)
         t_atac = S.BatchTiles(atac, rows, want_lib=False)
-        la = one_direction(A, t_rna, t_atac, time_adam)
-        finish_direction(A, time_adam)
-        lb = one_direction(Bd, t_atac, t_rna, time_adam)
-        finish_direction(Bd, time_adam)
-        return la, lb
+        if side is None:
+            la = one_direction(A, t_rna, t_atac, time_adam)
+            finish_direction(A, time_adam)
+            lb = one_direction(Bd, t_atac, t_rna, time_adam)
+            finish_direction(Bd, time_adam)
+            return la, lb
+        # the two predictors share nothing but the minibatch: one stream each, both after the tile-list build
+        ev = torch.cuda.Event()
+        ev.record()
+        for t in (t_rna, t_atac):
+            for x in (t.ptr, t.key, t.val, t.lib, t.nnan, t.rows):
+                if x is not None:
+                    for st in side:
+                        x.record_stream(st)
+        out = []
+        for st, (D, tx, ty) in zip(side, ((A, t_rna, t_atac), (Bd, t_atac, t_rna))):
+            with torch.cuda.stream(st):
+                st.wait_event(ev)
+                out.append(one_direction(D, tx, ty, time_adam))
+                finish_direction(D, time_adam)
+        return out[0], out[1]
+
+    side = (torch.cuda.Stream(), torch.cuda.Stream()) if a.streams == 2 else None
 
     def barrier():
         if world > 1:
@@ -216,7 +236,7 @@ def main():
         "config": {"workload": f"{a.workload}: {a.cells} cells x {a.genes} genes (NB) x {a.peaks} peaks (Bernoulli), "
                                f"batch {a.batch}/GPU, hidden {a.hidden}, dropout {a.dropout}, both directions per step",
                    "cells_resident_per_gpu": cells_here, "nnz_per_cell_rna": round(nnz_r, 1),
-                   "nnz_per_cell_atac": round(nnz_a, 1), "precision": a.precision, "parallelism": f"dp{world}",
+                   "nnz_per_cell_atac": round(nnz_a, 1), "precision": a.precision, "parallelism": f"dp{world}", "streams": a.streams,
                    "trained_params": n_params, "final_losses": losses},
         "roofline": {"kernel": "adamw_kernel (fused multi-tensor AdamW)", "bound": "hbm", "achieved": adam_gbs,
                      "peak": 8000.0, "unit": "GB/s", "frac": adam_gbs / 8000.0, "traffic": traffic,
