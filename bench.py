@@ -200,6 +200,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         la, lb = step(time_adam=True)
+    t_host = time.perf_counter() - t0             # host enqueue time of the timed steps (diagnostic)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -237,6 +238,7 @@ def main():
                                f"batch {a.batch}/GPU, hidden {a.hidden}, dropout {a.dropout}, both directions per step",
                    "cells_resident_per_gpu": cells_here, "nnz_per_cell_rna": round(nnz_r, 1),
                    "nnz_per_cell_atac": round(nnz_a, 1), "precision": a.precision, "parallelism": f"dp{world}", "streams": a.streams,
+                   "host_enqueue_ms_per_step": round(1e3 * t_host / a.steps, 3),
                    "trained_params": n_params, "final_losses": losses},
         "roofline": {"kernel": "adamw_kernel (fused multi-tensor AdamW)", "bound": "hbm", "achieved": adam_gbs,
                      "peak": 8000.0, "unit": "GB/s", "frac": adam_gbs / 8000.0, "traffic": traffic,
