@@ -78,6 +78,15 @@ int scp_ln_act_fwd(const float* Y, long ldy, long slab_stride, int nslab, const 
                    const float* beta, int B, int H, float eps, float slope, float p_drop, uint64_t seed,
                    float* xhat /* [B][ldx] saved for backward, nullable */, long ldx, float* rstd /* [B] */,
                    float* out, long ldo, void* stream);
+/* BatchNorm1d (placed after the activation, utils.py:61-62) + the layer's Dropout: batch statistics (training:
+ * biased variance for the output, unbiased for the running estimate, momentum update in place) or running statistics
+ * (eval); save_mean / save_rstd [H] feed the backward */
+int scp_bn_fwd(const float* x, long ldx, int B, int H, const float* gamma, const float* beta, float* run_mean,
+               float* run_var, int training, float momentum, float eps, float p_drop, uint64_t seed, float* save_mean,
+               float* save_rstd, float* y, long ldy, void* stream);
+int scp_bn_bwd(const float* dy, long lddy, const float* x, long ldx, int B, int H, const float* gamma,
+               const float* save_mean, const float* save_rstd, int training, float p_drop, uint64_t seed, float* dx,
+               long lddx, float* dgamma, float* dbeta, void* stream);
 int scp_ln_act_bwd_grid(int B);   /* partials_ws needs grid*3*H floats */
 int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, long ldx, const float* rstd, const float* gamma,
                    const float* beta, int B, int H, float slope, float p_drop, uint64_t seed, float* dY, long ldy,

@@ -441,3 +441,121 @@ extern "C" int scp_colsum(const float* X, long ld, int rows, int cols, float* ou
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
+
+// ---- BatchNorm1d (training statistics / running statistics) + dropout --------------------------------------------
+// The reference places BatchNorm1d AFTER the activation and before Dropout (utils.py:61-63).  Column statistics over
+// the batch: one workgroup owns 32 columns (32 x 8 threads, 8 row groups), two passes (mean, then centred second
+// moment) like the CPU oracle, fixed-order combination of the row groups -> deterministic.
+__device__ __forceinline__ float bn_group_sum(float v, float (*red)[32], int cx, int ry) {
+  __syncthreads();
+  red[ry][cx] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) s += red[k][cx];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, long ldx, int B, int H,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                     int training, float momentum, float eps, float p_drop,
+                                                     uint64_t seed, float* __restrict__ save_mean,
+                                                     float* __restrict__ save_rstd, float* __restrict__ y, long ldy) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  const bool ok = c < H;
+  float mean = 0.f, rstd = 1.f;
+  if (training) {
+    float s = 0.f;
+    if (ok)
+      for (int r = ry; r < B; r += 8) s += x[(long)r * ldx + c];
+    mean = bn_group_sum(s, red, cx, ry) / (float)B;
+    float q = 0.f;
+    if (ok)
+      for (int r = ry; r < B; r += 8) {
+        float d = x[(long)r * ldx + c] - mean;
+        q += d * d;
+      }
+    float var = bn_group_sum(q, red, cx, ry) / (float)B;
+    rstd = 1.f / sqrtf(var + eps);
+    if (ok && ry == 0) {
+      if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      if (run_var) run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)B / (float)max(B - 1, 1));
+    }
+  } else if (ok) {
+    mean = run_mean[c];
+    rstd = 1.f / sqrtf(run_var[c] + eps);
+  }
+  if (!ok) return;
+  if (ry == 0) {
+    save_mean[c] = mean;
+    save_rstd[c] = rstd;
+  }
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  for (int r = ry; r < B; r += 8) {
+    float v = (x[(long)r * ldx + c] - mean) * rstd * g + bt;
+    y[(long)r * ldy + c] = v * keep_scale(seed, (uint64_t)r * H + c, p_drop);
+  }
+}
+
+// dx, dgamma, dbeta.  training: dx = g*rstd*(dy' - mean(dy') - xhat*mean(dy'*xhat)); eval: dx = g*rstd*dy'
+// (dy' = dy with the dropout mask of the forward pass recomputed from the seed)
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                     long ldx, int B, int H, const float* __restrict__ gamma,
+                                                     const float* __restrict__ save_mean,
+                                                     const float* __restrict__ save_rstd, int training, float p_drop,
+                                                     uint64_t seed, float* __restrict__ dx, long lddx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  const bool ok = c < H;
+  const float mean = ok ? save_mean[c] : 0.f, rstd = ok ? save_rstd[c] : 1.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok)
+    for (int r = ry; r < B; r += 8) {
+      float g = dy[(long)r * lddy + c] * keep_scale(seed, (uint64_t)r * H + c, p_drop);
+      float xh = (x[(long)r * ldx + c] - mean) * rstd;
+      s1 += g;
+      s2 += g * xh;
+    }
+  s1 = bn_group_sum(s1, red, cx, ry);
+  s2 = bn_group_sum(s2, red, cx, ry);
+  if (!ok) return;
+  if (ry == 0) {
+    if (dgamma) dgamma[c] = s2;
+    if (dbeta) dbeta[c] = s1;
+  }
+  const float g_ = (gamma ? gamma[c] : 1.f) * rstd;
+  const float m1 = training ? s1 / (float)B : 0.f, m2 = training ? s2 / (float)B : 0.f;
+  for (int r = ry; r < B; r += 8) {
+    float g = dy[(long)r * lddy + c] * keep_scale(seed, (uint64_t)r * H + c, p_drop);
+    float xh = (x[(long)r * ldx + c] - mean) * rstd;
+    dx[(long)r * lddx + c] = g_ * (g - m1 - xh * m2);
+  }
+}
+
+extern "C" int scp_bn_fwd(const float* x, long ldx, int B, int H, const float* gamma, const float* beta, float* run_mean,
+                          float* run_var, int training, float momentum, float eps, float p_drop, uint64_t seed,
+                          float* save_mean, float* save_rstd, float* y, long ldy, void* stream_) {
+  SCP_CHECK(B > 0 && H > 0 && x && y && save_mean && save_rstd, SCP_ERR_ARG, "scp_bn_fwd: bad argument");
+  SCP_CHECK(training || (run_mean && run_var), SCP_ERR_ARG, "scp_bn_fwd: eval mode needs running statistics");
+  SCP_CHECK((gamma == nullptr) == (beta == nullptr), SCP_ERR_ARG, "scp_bn_fwd: gamma and beta go together");
+  SCP_CHECK(p_drop >= 0.f && p_drop < 1.f, SCP_ERR_ARG, "scp_bn_fwd: dropout p must be in [0,1)");
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream_, x, ldx, B, H, gamma, beta,
+                     run_mean, run_var, training, momentum, eps, p_drop, seed, save_mean, save_rstd, y, ldy);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_bn_bwd(const float* dy, long lddy, const float* x, long ldx, int B, int H, const float* gamma,
+                          const float* save_mean, const float* save_rstd, int training, float p_drop, uint64_t seed,
+                          float* dx, long lddx, float* dgamma, float* dbeta, void* stream_) {
+  SCP_CHECK(B > 0 && H > 0 && dy && x && dx && save_mean && save_rstd, SCP_ERR_ARG, "scp_bn_bwd: bad argument");
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream_, dy, lddy, x, ldx, B, H, gamma,
+                     save_mean, save_rstd, training, p_drop, seed, dx, lddx, dgamma, dbeta);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}

@@ -330,6 +330,55 @@ def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------
+# BatchNorm1d (+ the layer's dropout), utils.py:61-63
+# ------------------------------------------------------------------------------------------------
+class BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, training, momentum, eps, p_drop, seed):
+        L = _lib.lib()
+        x = _f32c(x)
+        _lib.require_cuda(x)
+        B, H = x.shape
+        y = torch.empty_like(x)
+        mean = _empty((H,), x)
+        rstd = _empty((H,), x)
+        _lib.check(L.scp_bn_fwd(x.data_ptr(), H, B, H, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean),
+                                _lib.ptr(run_var), int(training), float(momentum), float(eps), float(p_drop), int(seed),
+                                mean.data_ptr(), rstd.data_ptr(), y.data_ptr(), H, _lib.stream()), "scp_bn_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.cfg = (bool(training), float(p_drop), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, gamma, mean, rstd = ctx.saved_tensors
+        training, p_drop, seed = ctx.cfg
+        dy = _f32c(dy)
+        B, H = x.shape
+        dx = torch.empty_like(x)
+        dg = _empty((H,), x) if gamma is not None else None
+        db = _empty((H,), x) if gamma is not None else None
+        _lib.check(L.scp_bn_bwd(dy.data_ptr(), H, x.data_ptr(), H, B, H, _lib.ptr(gamma), mean.data_ptr(),
+                                rstd.data_ptr(), int(training), p_drop, seed, dx.data_ptr(), H, _lib.ptr(dg),
+                                _lib.ptr(db), _lib.stream()), "scp_bn_bwd")
+        return dx, dg, db, None, None, None, None, None, None, None
+
+
+def batch_norm(x, bn, training, p_drop=0.0, seed=0):
+    """nn.BatchNorm1d `bn` applied by the HIP kernel (batch statistics + in-place running-statistics update when
+    training and tracking, running statistics otherwise), followed by dropout p_drop."""
+    use_batch = training or bn.running_mean is None
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = bn.momentum
+    if mom is None:                               # cumulative moving average
+        mom = 1.0 / float(bn.num_batches_tracked) if (training and bn.num_batches_tracked is not None) else 0.0
+    return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                             bn.running_var if bn.track_running_stats else None, use_batch, mom, bn.eps, p_drop, seed)
+
+
+# ------------------------------------------------------------------------------------------------
 # fused decoders + losses
 # ------------------------------------------------------------------------------------------------
 def _dec_ws(B, F, K, dev):

@@ -72,11 +72,9 @@ class HipFCNN(nn.Sequential):
                                _slope_of(act), fused_p, ops.next_seed() if fused_p > 0 else 0,
                                1e-5 if ln is None else ln.eps)
             if bn is not None:
-                # BatchNorm1d sits after the activation in the reference (utils.py:61-62); column statistics
-                # go through torch's batch_norm op on the GPU for now (non-default configuration)
-                x = bn(x)
-                if p > 0:
-                    x = F.dropout(x, p, True)
+                # BatchNorm1d sits after the activation in the reference (utils.py:61-62): column statistics,
+                # running-statistics update and the layer's dropout in one HIP kernel
+                x = ops.batch_norm(x, bn, self.training, p, ops.next_seed() if p > 0 else 0)
         return x
 
 

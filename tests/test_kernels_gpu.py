@@ -420,3 +420,42 @@ def test_tiles_to_dense(S):
     rows = rng.permutation(200)[:130]
     t = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(m, S.dev), rows)
     np.testing.assert_array_equal(t.to_dense().cpu().numpy(), np.asarray(m[rows].todense(), dtype=np.float32))
+
+
+@pytest.mark.parametrize("B,H", [(130, 77), (64, 900)])
+def test_batch_norm_kernel(S, B, H):
+    """scp_bn_fwd / scp_bn_bwd against the oracle's BatchNorm1d restatement (training statistics, running-statistics
+    update, eval mode) and torch autograd of it on the CPU."""
+    O = S.O
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(B, H, generator=g) * 2 + 0.5
+    w = torch.rand(H, generator=g) + 0.5; b = torch.randn(H, generator=g)
+    dout = torch.randn(B, H, generator=g)
+    rm0 = torch.randn(H, generator=g) * 0.1; rv0 = torch.rand(H, generator=g) + 0.5
+    for training in (True, False):
+        xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        sd = {"bn.weight": wr, "bn.bias": br, "bn.running_mean": rm0.clone(), "bn.running_var": rv0.clone(),
+              "bn.num_batches_tracked": torch.tensor(0)}
+        yr = O.batch_norm(xr, sd, "bn", training)
+        (yr * dout).sum().backward()
+        bn = torch.nn.BatchNorm1d(H).to(S.dev)
+        with torch.no_grad():
+            bn.weight.copy_(w); bn.bias.copy_(b); bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+        xd = x.clone().to(S.dev).requires_grad_(True)
+        yd = S.ops.batch_norm(xd, bn, training)
+        (yd * dout.to(S.dev)).sum().backward()
+        close(yd, yr, rtol=1e-5, atol=1e-5, what="bn y")
+        close(xd.grad, xr.grad, rtol=1e-4, atol=2e-5, what="bn dx")
+        close(bn.weight.grad, wr.grad, rtol=1e-4, atol=1e-4, what="bn dgamma")
+        close(bn.bias.grad, br.grad, rtol=1e-4, atol=1e-4, what="bn dbeta")
+        close(bn.running_mean, sd["bn.running_mean"], rtol=1e-5, atol=1e-6, what="bn running_mean")
+        close(bn.running_var, sd["bn.running_var"], rtol=1e-5, atol=1e-6, what="bn running_var")
+        assert int(bn.num_batches_tracked) == int(sd["bn.num_batches_tracked"])
+    # dropout fused behind it: the backward recomputes the same mask
+    bn = torch.nn.BatchNorm1d(H).to(S.dev)
+    xd = x.clone().to(S.dev).requires_grad_(True)
+    yd = S.ops.batch_norm(xd, bn, True, 0.3, 1234)
+    keep = (yd != 0).float()
+    assert 0.55 < float(keep.mean()) < 0.85
+    y0 = S.ops.batch_norm(x.clone().to(S.dev), torch.nn.BatchNorm1d(H).to(S.dev), True)
+    close(yd, y0 * keep / 0.7, rtol=1e-5, atol=1e-6, what="bn dropout scale")
