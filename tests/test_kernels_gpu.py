@@ -459,3 +459,34 @@ def test_batch_norm_kernel(S, B, H):
     assert 0.55 < float(keep.mean()) < 0.85
     y0 = S.ops.batch_norm(x.clone().to(S.dev), torch.nn.BatchNorm1d(H).to(S.dev), True)
     close(yd, y0 * keep / 0.7, rtol=1e-5, atol=1e-6, what="bn dropout scale")
+
+
+@pytest.mark.parametrize("binary", [False, True])
+@pytest.mark.parametrize("density", [0.35, 0.9])
+def test_first_layer_bf16_dense_blocks(S, binary, density):
+    """Blocks far denser than the per-thread entry slots of the bf16 first-layer kernels (overflow path: extra
+    entries scattered by the slow loop, the LDS buffer cleared wholesale instead of un-scattered), mixed with sparse
+    feature ranges, forward and weight gradient, several K-steps per slab."""
+    S.ops.set_precision("bf16")
+    rng = np.random.default_rng(int(density * 100) + binary)
+    B, F, H = 300, 1500, 72
+    import scipy.sparse as sp
+    dense = rand_csr(rng, B, 700, density, binary=binary)
+    thin = rand_csr(rng, B, F - 700, 0.02, binary=binary)
+    m = sp.hstack([thin[:, :400], dense, thin[:, 400:]]).tocsr(); m.sort_indices()
+    X = torch.tensor(np.asarray(m.todense(), dtype=np.float32))
+    tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(m, S.dev, binary=binary), np.arange(B))
+    g = torch.Generator().manual_seed(1)
+    W = (torch.randn(H, F, generator=g) * 0.05).to(S.dev).requires_grad_(True)
+    b = torch.zeros(H, device=S.dev, requires_grad=True)
+    dout = torch.randn(B, H, generator=g).to(S.dev)
+    for _ in range(2):                            # twice: buffers / tags of a previous launch must not leak
+        W.grad = None
+        out = S.ops.fcnn_layer(tiles, None, W, b, None, None, 1.0)
+        out.backward(dout)
+        Xb, Wb = X.bfloat16().double(), W.detach().cpu().bfloat16().double()
+        ref = Xb @ Wb.t()
+        close(out, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()), what="dense-block fwd")
+        ref_dW = dout.cpu().bfloat16().double().t() @ Xb
+        close(W.grad, ref_dW, rtol=1e-4, atol=1e-4 * float(ref_dW.abs().max()), what="dense-block dW")
+    S.ops.set_precision("fp32")
