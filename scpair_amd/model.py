@@ -482,7 +482,7 @@ class scPair_object():
             c = None if cov is None else cov[r0:r0 + len(rows)]
             lib = ty.lib.reshape(-1, 1) if use_lib else None
             if likelihood == "gau":
-                loss = eval_net(tx, ycsr.to_dense(rows).to(self.device), lib, encoder, decoder, likelihood,
+                loss = eval_net(tx, ty.to_dense(), lib, encoder, decoder, likelihood,
                                 add_cov=c is not None, input_batch=c, output_batch=c)
                 cnt = torch.tensor(float(len(rows) * ycsr.n_cols), dtype=torch.float64, device=self.device)
             else:

@@ -86,17 +86,15 @@ class DeviceCSR:
         return int((ip[rows_host + 1] - ip[rows_host]).sum())
 
     def to_dense(self, rows=None):
-        """Dense fp32 copy (tests / small inference only)."""
-        ip = self.indptr_host
-        n = self.shape[0]
-        idx = self.indices.cpu().numpy()[: self.nnz]
-        val = np.ones(idx.shape[0], np.float32) if self.values is None else self.values.cpu().numpy()[: self.nnz]
-        out = np.zeros(self.shape, np.float32)
-        r = np.repeat(np.arange(n), np.diff(ip))
-        out[r, idx] = val
-        if rows is not None:
-            out = out[np.asarray(rows)]
-        return torch.from_numpy(out)
+        """Dense fp32 [len(rows), n_cols] tensor on the device (labels of the Gaussian / ZINB losses, small
+        inference), densified on the GPU through the tile list."""
+        rows = np.arange(self.shape[0]) if rows is None else np.asarray(rows, dtype=np.int64)
+        out = []
+        for r0 in range(0, len(rows), 16384):
+            out.append(BatchTiles(self, rows[r0:r0 + 16384], want_lib=False).to_dense())
+        if not out:
+            return torch.zeros((0, self.shape[1]), dtype=torch.float32, device=self.device)
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
 
 
 class BatchTiles:
