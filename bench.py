@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2: the two directions (independent trainings, model.py:608) run on two HIP streams")
+    ap.add_argument("--fp32-exchange", action="store_true",
+                    help="N > 1: all-reduce the wide first-layer gradients in fp32 even in bf16 mode (default: bf16)")
     ap.add_argument("--zinb", action="store_true", help="C3: zero-inflated NB for RNA (the G x G dropout layer is live)")
     return ap.parse_args()
 
@@ -127,7 +129,7 @@ def main():
     sync = None
     if world > 1:
         from scpair_amd.distributed import GradSync
-        sync = GradSync()
+        sync = GradSync(compress=(a.precision == "bf16" and not a.fp32_exchange))
         for d_ in (A, Bd):
             sync.broadcast(list(d_.enc.parameters()) + list(d_.dec.parameters()))
 
@@ -238,6 +240,7 @@ def main():
                                f"batch {a.batch}/GPU, hidden {a.hidden}, dropout {a.dropout}, both directions per step",
                    "cells_resident_per_gpu": cells_here, "nnz_per_cell_rna": round(nnz_r, 1),
                    "nnz_per_cell_atac": round(nnz_a, 1), "precision": a.precision, "parallelism": f"dp{world}", "streams": a.streams,
+                   "grad_exchange": ("none" if world == 1 else ("bf16 wide + fp32 rest" if sync.compress else "fp32")),
                    "host_enqueue_ms_per_step": round(1e3 * t_host / a.steps, 3),
                    "trained_params": n_params, "final_losses": losses},
         "roofline": {"kernel": "adamw_kernel (fused multi-tensor AdamW)", "bound": "hbm", "achieved": adam_gbs,

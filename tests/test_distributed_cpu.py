@@ -14,11 +14,11 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, compress=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from scpair_amd.distributed import GradSync
-    sync = GradSync(big=1000)
+    sync = GradSync(big=1000, compress=compress)
     torch.manual_seed(0)
     # a tiny model with one "big" (>= big elements) and several small tensors
     W1 = torch.nn.Parameter(torch.randn(40, 50)); b1 = torch.nn.Parameter(torch.randn(40)); W2 = torch.nn.Parameter(torch.randn(3, 40))
@@ -71,3 +71,30 @@ def test_global_batch_gradient_equals_single_process(world):
         np.testing.assert_allclose(got, ref.grad.numpy(), rtol=1e-4, atol=1e-5)
     assert abs(gl - float(loss)) < 1e-5 * abs(float(loss))
     assert num == sum(range(1, world + 1)) and den == 2.0 * world
+
+
+def test_bf16_exchange_of_wide_gradients():
+    """compress=True: tensors >= `big` elements are all-reduced as bf16 (the wide first-layer dW in bf16 mode), the
+    rest in fp32: the wide gradient matches the single-process one to bf16 rounding, the small ones to fp32."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    grads, gl, num, den, weights = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    W1 = torch.randn(40, 50, requires_grad=True); b1 = torch.randn(40, requires_grad=True); W2 = torch.randn(3, 40, requires_grad=True)
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(10, 50, generator=g); Y = torch.randn(10, 3, generator=g)
+    loss = ((torch.relu(X @ W1.t() + b1) @ W2.t() - Y) ** 2).mean()
+    loss.backward()
+    scale = float(W1.grad.abs().max())
+    np.testing.assert_allclose(grads[0], W1.grad.numpy(), rtol=2e-2, atol=1e-2 * scale)        # bf16: 8 bits
+    assert np.abs(grads[0] - W1.grad.numpy()).max() > 0                                          # really compressed
+    for ref, got in zip((b1, W2), grads[1:]):
+        np.testing.assert_allclose(got, ref.grad.numpy(), rtol=1e-4, atol=1e-5)
