@@ -406,10 +406,59 @@ class scPair_object():
         return None if (v is None or self.cov is None) else v.to(self.device).float()
 
     def data_loader_builder(self):
-        """model.py:450-516 needs an AnnData object (anndata is not part of this build).  Build the three
-        '{modality}_{split}_mtx|_cov|_lib' dicts yourself (dense tensors, scipy CSR or DeviceCSR values) and call
-        train_predicting_networks(train, val, test) -- the seam the reference itself exposes."""
-        raise NotImplementedError(self.data_loader_builder.__doc__)
+        """model.py:450-516 for any AnnData-like `scobj` (attributes `.X` [cells x features: scipy sparse or array],
+        `.obs` [DataFrame with a 'scPair_split' column and the covariate columns], `.var` [DataFrame with a
+        'modality' column]; anndata itself is not needed).  Same covariate handling (one-hot for category/object
+        columns, z-score with the pandas sample std for numeric ones, discrete block first), same split dicts and
+        keys, same metadata frames -- but the count matrices stay sparse: each '{modality}_{split}_mtx' value is a
+        scipy CSR matrix (the reference densifies the whole object here, model.py:492-507), which
+        train_predicting_networks() puts into HBM as CSR."""
+        import pandas as pd
+        import scipy.sparse as sp
+        data = self.scobj
+        if data is None:
+            raise ValueError("data_loader_builder needs scobj (or call train_predicting_networks with your own dicts)")
+        obs = data.obs
+        cov = self.cov
+        discrete_cov, continuous_cov = [], []
+        if cov is not None:
+            for c in cov:
+                if obs[c].dtype.name == 'category' or obs[c].dtype.name == 'object':
+                    discrete_cov.append(pd.get_dummies(obs[c]).astype(int))
+                else:
+                    continuous_cov.append((obs[c] - obs[c].mean()) / obs[c].std())
+        self.cov_discrete = pd.concat(discrete_cov, axis=1) if len(discrete_cov) > 0 else None
+        self.cov_continuous = pd.concat(continuous_cov, axis=1) if len(continuous_cov) > 0 else None
+        parts = [p_ for p_ in (self.cov_discrete, self.cov_continuous) if p_ is not None]
+        self.cov_dummy = None if not parts else (parts[0] if len(parts) == 1 else pd.concat(parts, axis=1))
+        if self.cov_dummy is not None:
+            obs = pd.concat([obs['scPair_split'], self.cov_dummy], axis=1)       # model.py:477
+        X = data.X
+        X = sp.csr_matrix(X) if not sp.issparse(X) else X.tocsr()
+        split_of = np.asarray(data.obs['scPair_split'])
+        modality_of = np.asarray(data.var['modality'])
+        out = {}
+        for split in ['train', 'val', 'test']:
+            ridx = np.flatnonzero(split_of == split)
+            meta = obs.iloc[ridx].copy()
+            setattr(self, f'{split}_metadata', meta)
+            Xs = X[ridx]
+            d = {}
+            for modality in self.modality_names:
+                cidx = np.flatnonzero(modality_of == modality)
+                m = Xs[:, cidx].tocsr().astype(np.float32)
+                m.sort_indices()
+                d[f'{modality}_{split}_mtx'] = m
+                d[f'{modality}_{split}_cov'] = (torch.FloatTensor(self.cov_dummy.loc[meta.index].values.astype(np.float32))
+                                                if cov is not None else None)
+                if modality in ['Gene Expression', 'Peaks']:
+                    d[f'{modality}_{split}_lib'] = torch.from_numpy(np.asarray(m.sum(1), dtype=np.float32).reshape(-1, 1))
+            out[split] = d
+        self.data_loader_keys = [k for sp_ in ['train', 'val', 'test'] for k in out[sp_].keys()]
+        self.data_loader_dict_train, self.data_loader_dict_val, self.data_loader_dict_test = \
+            out['train'], out['val'], out['test']
+        self._csr_cache = {}
+        return self.data_loader_dict_train, self.data_loader_dict_val, self.data_loader_dict_test
 
     def set_data(self, train_data_dict, val_data_dict, test_data_dict=None):
         """Registers the split dicts (what data_loader_builder() stores at model.py:512-516)."""

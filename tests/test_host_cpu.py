@@ -113,3 +113,33 @@ def test_synthetic_generator_is_deterministic():
     assert (a["rna"] != b["rna"]).nnz == 0 and (a["atac"] != b["atac"]).nnz == 0
     assert a["rna"].has_canonical_format and a["atac"].has_canonical_format
     assert len(set(a["train"]) | set(a["val"]) | set(a["test"])) == 64
+
+
+@pytest.mark.parametrize("tag,cov", [("cov", ["labels", "depth"]), ("nocov", None)])
+def test_data_loader_builder_matches_reference(tag, cov):
+    """data_loader_builder on an AnnData-like object (model.py:450-516): same keys, matrices (kept sparse here),
+    covariate blocks, library sizes and metadata as the reference's builder (golden: tools/make_golden_loader.py)."""
+    import scipy.sparse as sp
+    import scpair_amd as S
+    from tests.util import load, make_mini_adata
+    gold = load("data_loader")
+    ad = make_mini_adata(seed=3)
+    obj = S.scPair_object(scobj=ad, cov=cov, modalities={"Gene Expression": "zinb", "Peaks": "ber"},
+                          device=torch.device("cpu"), save_model=False)
+    tr, va, te = obj.data_loader_builder()
+    n_checked = 0
+    for split, d in (("train", tr), ("val", va), ("test", te)):
+        for k, v in d.items():
+            gk = f"{tag}/{k}"
+            if v is None:
+                assert gk not in gold
+                continue
+            got = np.asarray(v.todense()) if sp.issparse(v) else v.numpy()
+            np.testing.assert_allclose(got, gold[gk], rtol=1e-6, atol=1e-6, err_msg=gk)
+            if k.endswith("_mtx"):
+                assert sp.issparse(v) and v.has_sorted_indices
+            n_checked += 1
+        meta = getattr(obj, f"{split}_metadata")
+        assert list(meta.index) == list(gold[f"{tag}/{split}_index"])
+        assert [str(c) for c in meta.columns] == list(gold[f"{tag}/{split}_columns"])
+    assert n_checked == len([k for k in gold.files if k.startswith(tag + "/") and not k.endswith(("_index", "_columns"))])

@@ -127,3 +127,25 @@ def test_vae_trajectory_fp32():
         assert np.max(np.abs(got - d["eval"][ep]) / np.abs(d["eval"][ep])) < 5e-4, (ep, got, d["eval"][ep])
     for k, v in enc.state_dict().items():
         assert float((v.cpu() - torch.tensor(d["enc_final/" + k])).abs().max()) < 2e-3, k
+
+
+def test_run_from_anndata_like_object():
+    """The reference's top-level workflow `scPair_object(scobj=adata, cov=[...]).run()` (model.py:517-526) on an
+    AnnData-like object: data_loader_builder keeps the matrices sparse, the predictors, embeddings and the
+    bidirectional mapping train on the GPU; every output has the reference's keys and shapes and finite values."""
+    import scpair_amd as S
+    from tests.util import make_mini_adata
+    ad = make_mini_adata(seed=5, n=400, g=40, p=60)
+    obj = S.scPair_object(scobj=ad, cov=["labels", "depth"], modalities={"Gene Expression": "zinb", "Peaks": "ber"},
+                          hidden_layer=[32, 8], batch_size=64, max_epochs=3, early_stopping_patience=2,
+                          device=torch.device("cuda:0"), save_model=False)
+    enc, dec, maps, emb, emb_mapped = obj.run()
+    n_train = int((ad.obs["scPair_split"] == "train").sum())
+    assert set(enc.keys()) == {"Gene Expression to Peaks", "Peaks to Gene Expression"} == set(dec.keys())
+    assert emb["Gene Expression_train"].shape == (n_train, 8) and emb["Peaks_train"].shape == (n_train, 8)
+    _, emb_df = obj.reference_embeddings()
+    assert list(emb_df["Gene Expression_train"].index) == list(obj.train_metadata.index)
+    for v in list(emb.values()) + list(emb_mapped.values()):
+        assert np.isfinite(np.asarray(v)).all()
+    pred = obj.predict()
+    assert pred["Peaks_test"].shape[1] == 60 and np.isfinite(pred["Peaks_test"]).all()
