@@ -145,6 +145,12 @@ int scp_ber_prob(const float* z, long ldz, int rows, int cols, const float* lrow
 int scp_relu_softmax_rows(const float* z, long ldz, int rows, int cols, const float* fs, int apply_relu,
                           float* scale, long lds, float* theta /* nullable */, long ldt, void* stream);
 
+/* ---- evaluation metrics (evaluator.py:14-71): neighbour counts behind FOSCTTM / FOSFTTM for paired embeddings
+ *      x, y [n][d]: lt12[i] = #{j: D[i][j] < D[i][i]}, lt21[i] = #{j: D[j][i] < D[i][i]},
+ *      gt12[i] = #{j: D[i][j] > D[i][i]} with D the direct-form squared distances; diag_ws: n floats ---- */
+int scp_fos_counts(const float* x, long ldx, const float* y, long ldy, int n, int d, float* diag_ws, int32_t* lt12,
+                   int32_t* lt21, int32_t* gt12, void* stream);
+
 /* ---- optimiser: torch.optim.AdamW step as the trainer configures it (model.py:698-701, 849-850, 982) ---- */
 #define SCP_ADAM_MAX_TENSORS 24
 typedef struct {

@@ -445,3 +445,27 @@ def run_direction(direction: Direction, xtr, ytr, libtr, xva, yva, libva, batche
         if ep > 1 and no_imp == patience:
             break
     return train_losses, val_losses, best_sd
+
+
+# ---- evaluation metrics (evaluator.py:14-71) -- test infrastructure like the rest of this file -----------------------
+def pairwise_sq_dists(x, y):
+    """evaluator.py:14-21: D[i][j] = sum_k (x[i][k] - y[j][k])^2, direct form."""
+    x = np.asarray(x); y = np.asarray(y)
+    return np.sum(np.square(x[:, :, None] - y.T[None, :, :]), 1)
+
+
+def foscttm(domain1, domain2):
+    """evaluator.py:24-46 -> (average, per-cell 1->2 fractions, per-cell 2->1 fractions)."""
+    n = np.asarray(domain1).shape[0]
+    D = pairwise_sq_dists(domain1, domain2)
+    f12 = np.array([np.sum(D[i, i] > D[i, :]) / (n - 1) for i in range(n)])
+    f21 = np.array([np.sum(D[i, i] > D[:, i]) / (n - 1) for i in range(n)])
+    return (f21.sum() / n + f12.sum() / n) / 2, f12, f21
+
+
+def fosfttm(query, reference):
+    """evaluator.py:49-71 -> (average, per-cell fractions)."""
+    n = np.asarray(reference).shape[0]
+    D = pairwise_sq_dists(query, reference)
+    f = np.array([np.sum(D[i, i] < D[i, :]) / (n - 1) for i in range(n)])
+    return f.sum() / n, f

@@ -12,5 +12,6 @@ from .model import (Input_Module, LazyGPUDataset, Module_Module, Output_Module_B
 from .pairedVAE import VAE_DECODER, VAE_ENCODER  # noqa: F401
 from .sparse import BatchTiles, DeviceCSR  # noqa: F401
 from .ops import FusedAdamW, get_precision, set_precision  # noqa: F401
+from .evaluator import FOSCTTM, FOSFTTM  # noqa: F401
 
 __version__ = "0.1.0"

@@ -490,3 +490,22 @@ def test_first_layer_bf16_dense_blocks(S, binary, density):
         ref_dW = dout.cpu().bfloat16().double().t() @ Xb
         close(W.grad, ref_dW, rtol=1e-4, atol=1e-4 * float(ref_dW.abs().max()), what="dense-block dW")
     S.ops.set_precision("fp32")
+
+
+def test_foscttm_fosfttm_gpu(S):
+    """scp_fos_counts behind scpair_amd.evaluator against the reference's evaluator outputs (golden) and, on a
+    ragged larger case, against the oracle; counts are integers, so away from exact distance ties the results agree
+    to the last bit of the final division."""
+    from scpair_amd import evaluator as E
+    g = U.load("eval_fos")
+    assert abs(E.FOSCTTM(g["x"], g["y"]) - float(g["foscttm"])) < 1e-9
+    f12, f21 = E.FOSCTTM(g["x"], g["y"], output_full=True)
+    np.testing.assert_allclose(f12, g["f12_sorted"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(f21, g["f21_sorted"], rtol=0, atol=1e-12)
+    assert abs(E.FOSFTTM(g["x"], g["y"]) - float(g["fosfttm"])) < 1e-9
+    np.testing.assert_allclose(E.FOSFTTM(g["x"], g["y"], output_full=True), g["fosfttm_full"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(E.FOSFTTM(g["x"], g["y"], output_full=True, sort=True), g["fosfttm_sorted"], rtol=0, atol=1e-12)
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(1000, 70)).astype(np.float32); y = (x + 5 * rng.normal(size=x.shape)).astype(np.float32)
+    av, _, _ = S.O.foscttm(x, y)
+    assert abs(E.FOSCTTM(x, y) - av) < 2e-6       # fp32 summation order can flip a handful of near-ties in 1e6 pairs

@@ -271,3 +271,15 @@ def test_training_trajectory(name):
         emb = O.input_module(best[0], xtr, cov["train"], True, c["batchnorm"], 0.01, False)[0]
         key = "emb/" + list(c["modalities"].keys())[di] + "_train"
         close(emb.detach(), d[key], rtol=5e-3, atol=1e-3)
+
+
+def test_eval_metrics_oracle_vs_reference():
+    """FOSCTTM / FOSFTTM restatement (oracle/ref_cpu.py) against the reference's evaluator outputs."""
+    from oracle import ref_cpu as O
+    g = U.load("eval_fos")
+    av, f12, f21 = O.foscttm(g["x"], g["y"])
+    assert abs(av - float(g["foscttm"])) < 1e-12
+    np.testing.assert_array_equal(np.sort(f12), g["f12_sorted"]); np.testing.assert_array_equal(np.sort(f21), g["f21_sorted"])
+    av2, f = O.fosfttm(g["x"], g["y"])
+    assert abs(av2 - float(g["fosfttm"])) < 1e-12
+    np.testing.assert_array_equal(f, g["fosfttm_full"])
