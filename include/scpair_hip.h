@@ -145,6 +145,16 @@ int scp_ber_prob(const float* z, long ldz, int rows, int cols, const float* lrow
 int scp_relu_softmax_rows(const float* z, long ldz, int rows, int cols, const float* fs, int apply_relu,
                           float* scale, long lds, float* theta /* nullable */, long ldt, void* stream);
 
+/* ---- (ZI)NB decoder heads on materialised pre-activations (ZINB predictor with its G x G zero-inflation layer,
+ *      model.py:228-259; loss.py:46-51; scVI_distribution.py:29-105), dispersion 'feature-cell', no feature factor:
+ *      z [B][G] = output_mean Linear output, pi [B][G] zero-inflation logits or null (plain NB), y dense labels,
+ *      L [B] library term.  fwd: loss, lse [B], T [B] (kept for bwd), part: B doubles.  bwd: dz, dpi, dL (nullable) ---- */
+int scp_raw_rows_fwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy, const float* L,
+                     int B, int G, float* lse, float* T, double* part, float* loss, void* stream);
+int scp_raw_rows_bwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy, const float* L,
+                     const float* lse, const float* T, const float* gout, int B, int G, float* dz, long lddz,
+                     float* dpi, long lddp, float* dL, void* stream);
+
 /* ---- evaluation metrics (evaluator.py:14-71): neighbour counts behind FOSCTTM / FOSFTTM for paired embeddings
  *      x, y [n][d]: lt12[i] = #{j: D[i][j] < D[i][i]}, lt21[i] = #{j: D[j][i] < D[i][i]},
  *      gt12[i] = #{j: D[i][j] > D[i][i]} with D the direct-form squared distances; diag_ws: n floats ---- */

@@ -159,6 +159,59 @@ __device__ __forceinline__ float lgamma_terms(float x, float theta) {
   return lgammaf(x + theta) - lgammaf(theta) - lgammaf(x + 1.f);
 }
 
+// math flavour: accurate libm in the fp32-equivalent mode (NS=3), hardware exp/log/rcp in bf16 mode (NS=1)
+template <bool FAST> __device__ __forceinline__ float exp_(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FAST> __device__ __forceinline__ float log_(float x) { return FAST ? __logf(x) : logf(x); }
+template <bool FAST> __device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ float sigm_(float x) { return div_<FAST>(1.f, 1.f + exp_<FAST>(-x)); }
+
+// lgamma(y+th) - lgamma(th) - lgamma(y+1) and digamma(y+th) - digamma(th).  For small integer counts the exact
+// identities  sum_{i<y} log((th+i)/(i+1))  and  sum_{i<y} 1/(th+i)  avoid both the slow lgammaf/digamma evaluations
+// and the cancellation of lgamma(y+th)-lgamma(th) at large theta.  The sums are evaluated without a transcendental
+// per term: the log of a running product (one log at the end; the product of <= 12 factors <= 1035 fits fp32) and
+// a running fraction N/D (one division at the end).  For th > 1024 the factors are expanded around th instead
+// (i/th < 0.011: three series terms leave < 4e-9 per factor).
+template <bool FAST>
+__device__ __forceinline__ float lgam3(float y, float th) {
+  if (y <= 12.f && y == floorf(y)) {
+    float den = 1.f;
+    if (th > 1024.f) {
+      for (float i = 1.f; i < y; i += 1.f) den *= i + 1.f;
+      float it = div_<FAST>(1.f, th);
+      float s1 = 0.5f * y * (y - 1.f);                          // sum i
+      float s2 = (y - 1.f) * y * (2.f * y - 1.f) * (1.f / 6.f);  // sum i^2
+      float s3 = s1 * s1;                                       // sum i^3
+      return y * log_<FAST>(th) + it * (s1 - it * (0.5f * s2 - it * (1.f / 3.f) * s3)) - log_<FAST>(den);
+    }
+    float num = 1.f;
+    for (float i = 0.f; i < y; i += 1.f) {
+      num *= th + i;
+      den *= i + 1.f;
+    }
+    return log_<FAST>(div_<FAST>(num, den));
+  }
+  return lgammaf(y + th) - lgammaf(th) - lgammaf(y + 1.f);
+}
+template <bool FAST>
+__device__ __forceinline__ float digam2(float y, float th) {
+  if (y <= 12.f && y == floorf(y)) {
+    if (th > 1024.f) {
+      float it = div_<FAST>(1.f, th);
+      float s1 = 0.5f * y * (y - 1.f);
+      float s2 = (y - 1.f) * y * (2.f * y - 1.f) * (1.f / 6.f);
+      return it * (y - it * (s1 - it * s2));
+    }
+    float n = 0.f, d = 1.f;
+    for (float i = 0.f; i < y; i += 1.f) {
+      float x = th + i;
+      n = n * x + d;
+      d *= x;
+    }
+    return div_<FAST>(n, d);
+  }
+  return digammaf_pos(y + th) - digammaf_pos(th);
+}
+
 // counter-based RNG for dropout masks: one 32-bit hash per (seed, element index); reproducible in backward
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;

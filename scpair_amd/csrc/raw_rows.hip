@@ -1,0 +1,171 @@
+// Row kernels for the (ZI)NB decoders whose pre-activations are materialised: the ZINB predictor, whose G x G
+// zero-inflation layer needs px_mu as a GEMM operand (model.py:228-259), and the VAE decoder heads.
+//
+//   z  [B][G]  pre-activation of output_mean's Linear          pi [B][G] zero-inflation logits (null: plain NB)
+//   a = relu(z), scale = softmax_row(a), mu = L[b] * scale, theta = exp(a)   (dispersion 'feature-cell')
+//   loss = -mean_{b,j} log (ZI)NB(y; mu, theta, pi)            scVI_distribution.py:29-105, loss.py:46-51
+//
+// One workgroup per cell row.  Forward: row log-sum-exp, log-likelihood sum and T = sum_j mu_j dll/dmu_j (the
+// softmax backward needs it); backward recomputes the cheap element terms and writes dz and dpi.  This replaces
+// relu + softmax + scale + exp + the element-wise likelihood and their autograd (10+ passes over [B][G]) by
+// 4 reads forward and 3 reads + 2 writes backward.
+#include "common.h"
+#include "scpair_hip.h"
+
+struct RawTerms {
+  float ll, dm, dth, dp, mu, th;
+};
+
+// element terms shared by forward and backward (same arithmetic as nbll_fwd/bwd_kernel in elementwise.hip)
+template <bool WANT_LL, bool WANT_GRAD>
+__device__ __forceinline__ RawTerms raw_terms(float zv, float xv, float L, float lse, bool zi, float pv) {
+  const float eps = 1e-8f;
+  RawTerms t;
+  float a = fmaxf(zv, 0.f);
+  float scale = expf(a - lse);
+  t.mu = L * scale;
+  t.th = expf(a);
+  float m = t.mu, th = t.th;
+  float s = th + m + eps;
+  float lt = logf(th + eps), ls = logf(s);
+  bool nz = xv > eps, zero = xv < eps;
+  t.ll = 0.f; t.dm = 0.f; t.dth = 0.f; t.dp = 0.f;
+  float base = th * (lt - ls);
+  if (WANT_LL) {
+    float c1 = base + xv * (logf(m + eps) - ls) + (nz ? lgam3<false>(xv, th) : 0.f);
+    if (!zi) {
+      t.ll = c1;
+    } else {
+      float sp = softplus_t(-pv);
+      float tt = -pv + base;
+      float c0 = softplus_t(tt) - sp;
+      t.ll = (zero ? c0 : 0.f) + (nz ? (c1 - pv - sp) : 0.f);
+    }
+  }
+  if (WANT_GRAD) {
+    float dt_dmu = -th / s;
+    float dt_dth = lt - ls + th / (th + eps) - th / s;
+    float dig = nz ? digam2<false>(xv, th) : 0.f;
+    float dm_nz = dt_dmu + xv * (1.f / (m + eps) - 1.f / s);
+    float dth_nz = dt_dth - xv / s + dig;
+    if (!zi) {
+      t.dm = dm_nz;
+      t.dth = dth_nz;
+    } else {
+      float tt = -pv + base;
+      float sig_t = tt > 20.f ? 1.f : sigmoidf_(tt);
+      float sig_npi = (-pv) > 20.f ? 1.f : sigmoidf_(-pv);
+      if (zero) {
+        t.dm = sig_t * dt_dmu;
+        t.dth = sig_t * dt_dth;
+        t.dp = -sig_t + sig_npi;
+      } else if (nz) {
+        t.dm = dm_nz;
+        t.dth = dth_nz;
+        t.dp = sig_npi - 1.f;
+      }
+    }
+  }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void raw_rows_fwd_kernel(const float* __restrict__ z, long ldz,
+                                                           const float* __restrict__ pi, long ldp,
+                                                           const float* __restrict__ y, long ldy,
+                                                           const float* __restrict__ Lrow, int B, int G,
+                                                           float* __restrict__ lse_out, float* __restrict__ T_out,
+                                                           double* __restrict__ part) {
+  __shared__ float red[16];
+  __shared__ double dred[8];
+  __shared__ float bc[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* zr = z + (long)b * ldz;
+  // pass 1: log-sum-exp of relu(z) (max first, then the sum)
+  float m = 0.f;                                   // relu(z) >= 0
+  for (int j = tid; j < G; j += 256) m = fmaxf(m, zr[j]);
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int j = tid; j < G; j += 256) se += expf(fmaxf(zr[j], 0.f) - m);
+  se = block_sum(se, red);
+  if (tid == 0) bc[0] = m + logf(se);
+  __syncthreads();
+  const float lse = bc[0], L = Lrow[b];
+  // pass 2: log-likelihood and T
+  const bool zi = pi != nullptr;
+  double ll = 0.0;
+  float T = 0.f;
+  for (int j = tid; j < G; j += 256) {
+    float pv = zi ? pi[(long)b * ldp + j] : 0.f;
+    RawTerms t = raw_terms<true, true>(zr[j], y[(long)b * ldy + j], L, lse, zi, pv);
+    ll += (double)t.ll;
+    T += t.mu * t.dm;
+  }
+  T = block_sum(T, red);
+  double lls = block_sum_d(ll, dred);
+  if (tid == 0) {
+    lse_out[b] = lse;
+    T_out[b] = T;
+    part[b] = lls;
+  }
+}
+
+__global__ void raw_rows_finish_kernel(const double* __restrict__ part, int B, double n_total, float* __restrict__ loss) {
+  __shared__ double dred[8];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < B; i += 256) s += part[i];
+  s = block_sum_d(s, dred);
+  if (threadIdx.x == 0) loss[0] = (float)(-s / n_total);
+}
+
+__global__ __launch_bounds__(256) void raw_rows_bwd_kernel(const float* __restrict__ z, long ldz,
+                                                           const float* __restrict__ pi, long ldp,
+                                                           const float* __restrict__ y, long ldy,
+                                                           const float* __restrict__ Lrow,
+                                                           const float* __restrict__ lse_in,
+                                                           const float* __restrict__ T_in,
+                                                           const float* __restrict__ gout, int B, int G,
+                                                           float* __restrict__ dz, long lddz, float* __restrict__ dpi,
+                                                           long lddp, float* __restrict__ dL) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float c = -(gout ? gout[0] : 1.f) / ((float)B * (float)G);
+  const float lse = lse_in[b], L = Lrow[b], T = T_in[b];
+  const bool zi = pi != nullptr;
+  for (int j = tid; j < G; j += 256) {
+    float zv = z[(long)b * ldz + j];
+    float pv = zi ? pi[(long)b * ldp + j] : 0.f;
+    RawTerms t = raw_terms<false, true>(zv, y[(long)b * ldy + j], L, lse, zi, pv);
+    float scale = t.mu / L;
+    // softmax backward (g_j = L dm_j): mu dm - scale T ; theta = exp(a) path: dth * th
+    float da = c * (t.mu * t.dm - scale * T + t.dth * t.th);
+    dz[(long)b * lddz + j] = zv > 0.f ? da : 0.f;
+    if (zi) dpi[(long)b * lddp + j] = c * t.dp;
+  }
+  if (dL && tid == 0) dL[b] = c * T / L;
+}
+
+extern "C" int scp_raw_rows_fwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy,
+                                const float* Lrow, int B, int G, float* lse, float* T, double* part, float* loss,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SCP_CHECK(B > 0 && G > 0 && z && y && Lrow && lse && T && part && loss, SCP_ERR_ARG, "scp_raw_rows_fwd: bad argument");
+  hipLaunchKernelGGL(raw_rows_fwd_kernel, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, B, G, lse, T, part);
+  SCP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(raw_rows_finish_kernel, dim3(1), dim3(256), 0, stream, part, B, (double)B * (double)G, loss);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_raw_rows_bwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy,
+                                const float* Lrow, const float* lse, const float* T, const float* gout, int B, int G,
+                                float* dz, long lddz, float* dpi, long lddp, float* dL, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SCP_CHECK(B > 0 && G > 0 && z && y && Lrow && lse && T && dz, SCP_ERR_ARG, "scp_raw_rows_bwd: bad argument");
+  SCP_CHECK((pi == nullptr) == (dpi == nullptr), SCP_ERR_ARG, "scp_raw_rows_bwd: pi and dpi go together");
+  hipLaunchKernelGGL(raw_rows_bwd_kernel, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, lse, T, gout, B, G,
+                     dz, lddz, dpi, lddp, dL);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}

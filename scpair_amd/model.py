@@ -194,14 +194,31 @@ class Output_Module_Raw(nn.Module):
         return px_mu_scale, px_theta, px_mu_rate, px_pi
 
     def fused_loss(self, latent_rep, output_batch, lib, latent_lib, labels, likelihood="nb"):
-        """raw_loss(labels, *forward(...)) for likelihood 'nb' in three fused kernel passes (row softmax statistics,
-        likelihood, gradients).  Returns None for 'zinb' (the G x G zero-inflation layer needs the materialised
-        form: forward() + raw_loss)."""
-        if likelihood != "nb":
+        """raw_loss(labels, *forward(...)): likelihood 'nb' in three fused decoder passes (row softmax statistics,
+        likelihood, gradients); 'zinb' through the materialised pre-activations and the fused row kernels.  Returns
+        None for the combinations without a fused form (feature factor / feature dispersion with 'zinb')."""
+        if likelihood not in ("nb", "zinb"):
             return None
         h = _cat_cov(latent_rep, output_batch)
         fs = self.feature_scalar if self.feature_factor == True else None  # noqa: E712
         thp = self.output_inverse_dispersion if self.dispersion == "feature" else None
+        lin = self.output_mean[0]
+        if likelihood == "zinb":
+            # The G x G zero-inflation layer needs px_mu as a GEMM operand, so the pre-activations are materialised:
+            # z = Linear(h) (MFMA GEMM), px_mu = relu(z), pi = Linear_GxG(px_mu) (library GEMM in bf16 mode), then
+            # softmax / exp / ZINB likelihood and their backward in the fused row kernels.
+            if fs is not None or thp is not None or self.zero_inflated != True:  # noqa: E712
+                return None
+            if self.sample_factor == True:  # noqa: E712
+                L = lib
+            elif latent_lib is not None:
+                L = torch.exp(self.transformation_function(latent_lib))
+            else:
+                raise Exception("The library size is missing. Please ensure that either the 'sample_factor' or "
+                                "'infer_library_size' parameter for the raw counts decoder is set to True.")
+            z = ops.linear(h, lin.weight, lin.bias)
+            pi = self.output_dropout(torch.relu(z))
+            return ops.raw_rows_loss(z, pi, L, labels.to_dense())
         if self.sample_factor == True:  # noqa: E712
             L, lat = lib, None
         elif latent_lib is not None:
@@ -210,7 +227,6 @@ class Output_Module_Raw(nn.Module):
         else:
             raise Exception("The library size is missing. Please ensure that either the 'sample_factor' or "
                             "'infer_library_size' parameter for the raw counts decoder is set to True.")
-        lin = self.output_mean[0]
         return ops.nb_decoder_loss(h, lin.weight, lin.bias, fs, thp, L, lat, labels)
 
 

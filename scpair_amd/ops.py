@@ -491,6 +491,51 @@ def nb_decoder_loss(h, W, b, fs, theta_param, lib_L, lat, tiles):
 
 
 # ------------------------------------------------------------------------------------------------
+# (ZI)NB loss on materialised pre-activations (ZINB predictor, VAE heads)
+# ------------------------------------------------------------------------------------------------
+class RawRowsLossFn(torch.autograd.Function):
+    """loss = raw_loss(y, L*softmax(relu(z)), exp(relu(z)), ., pi) (model.py:229-259 with dispersion 'feature-cell'
+    and no feature factor; loss.py:46-51) from the pre-activation z of output_mean's Linear, in one row kernel
+    forward and one backward.  pi = None: plain NB."""
+
+    @staticmethod
+    def forward(ctx, z, pi, L, y):
+        lib = _lib.lib()
+        z, y = _f32c(z), _f32c(y)
+        pi = None if pi is None else _f32c(pi)
+        Lr = _f32c(L).reshape(-1)
+        _lib.require_cuda(z, y, Lr)
+        B, G = z.shape
+        lse, T = _empty((B,), z), _empty((B,), z)
+        part = torch.empty(B, dtype=torch.float64, device=z.device)
+        loss = _empty((1,), z)
+        _lib.check(lib.scp_raw_rows_fwd(z.data_ptr(), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(), B, G,
+                                        lse.data_ptr(), T.data_ptr(), part.data_ptr(), loss.data_ptr(), _lib.stream()),
+                   "scp_raw_rows_fwd")
+        ctx.save_for_backward(z, pi, Lr, y, lse, T)
+        ctx.l_shape = L.shape
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.lib()
+        z, pi, Lr, y, lse, T = ctx.saved_tensors
+        B, G = z.shape
+        g = _f32c(g).reshape(1)
+        dz = torch.empty_like(z)
+        dpi = None if pi is None else torch.empty_like(pi)
+        dL = _empty((B,), z) if ctx.needs_input_grad[2] else None
+        _lib.check(lib.scp_raw_rows_bwd(z.data_ptr(), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(), lse.data_ptr(),
+                                        T.data_ptr(), g.data_ptr(), B, G, dz.data_ptr(), G, _lib.ptr(dpi), G,
+                                        _lib.ptr(dL), _lib.stream()), "scp_raw_rows_bwd")
+        return dz, dpi, (None if dL is None else dL.reshape(ctx.l_shape)), None
+
+
+def raw_rows_loss(z, pi, L, y):
+    return RawRowsLossFn.apply(z, pi, L, y)
+
+
+# ------------------------------------------------------------------------------------------------
 # masked MSE, reparameterisation + KL
 # ------------------------------------------------------------------------------------------------
 class MseMaskedFn(torch.autograd.Function):

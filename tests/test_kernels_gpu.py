@@ -17,10 +17,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def S():
+    import scpair_amd as pkg
+    import scpair_amd.loss, scpair_amd.model  # noqa: F401,E401
     import scpair_amd.ops as ops
     import scpair_amd.sparse as sparse
     from oracle import ref_cpu as O
-    return type("S", (), dict(ops=ops, sparse=sparse, O=O, dev=torch.device("cuda:0")))
+    return type("S", (), dict(pkg=pkg, ops=ops, sparse=sparse, O=O, dev=torch.device("cuda:0")))
 
 
 def relerr(a, b):
@@ -296,6 +298,51 @@ def test_decoders_larger_vs_oracle(S, B, F, K):
     close(l, lo, rtol=5e-5, atol=0, what="nb loss")
     for nm, a, r_ in [("dh", hd.grad, hr.grad), ("dW", Wd.grad, Wr.grad), ("db", bd.grad, br.grad)]:
         close(a, r_, rtol=5e-4, atol=5e-4 * float(r_.abs().max()), what=f"nb {nm}")
+
+
+@pytest.mark.parametrize("B,F,K,sf", [(130, 2051, 40, True), (67, 333, 11, False), (5, 1000, 8, True)])
+def test_zinb_row_loss_vs_oracle(S, B, F, K, sf):
+    """ZINB predictor head (pre-activations materialised, fused row kernels) against the CPU oracle: loss and the
+    gradients of the mean layer, the G x G zero-inflation layer, the latent input and the latent library size."""
+    O = S.O
+    S.ops.set_precision("fp32")
+    rng = np.random.default_rng(F + 1)
+    g = torch.Generator().manual_seed(F + 1)
+    h = torch.randn(B, K, generator=g) * 0.5
+    W = torch.randn(F, K, generator=g) * 0.3; b = torch.randn(F, generator=g) * 0.5
+    Wp = torch.randn(F, F, generator=g) * (0.5 / F ** 0.5); bp = torch.randn(F, generator=g) * 0.5
+    lat = torch.randn(B, 1, generator=g) + 4.0
+    yn = rand_csr(rng, B, F, 0.1)
+    ynd = torch.tensor(np.asarray(yn.todense(), dtype=np.float32))
+    lib = ynd.sum(1, keepdim=True)
+    ref = [t.clone().requires_grad_(True) for t in (h, W, b, Wp, bp, lat)]
+    sd = {"output_mean.0.weight": ref[1], "output_mean.0.bias": ref[2], "output_dropout.weight": ref[3],
+          "output_dropout.bias": ref[4]}
+    _, theta, rate, pi = O.output_raw(sd, ref[0], None, lib if sf else None, None if sf else ref[5], sf)
+    lo = O.raw_loss(ynd, rate, theta, pi, "zinb"); lo.backward()
+    dec = S.pkg.model.Output_Module_Raw(F, 0, [K], infer_library_size=not sf, sample_factor=sf).to(S.dev)
+    with torch.no_grad():
+        dec.output_mean[0].weight.copy_(W); dec.output_mean[0].bias.copy_(b)
+        dec.output_dropout.weight.copy_(Wp); dec.output_dropout.bias.copy_(bp)
+    hd, ld = h.clone().to(S.dev).requires_grad_(True), lat.clone().to(S.dev).requires_grad_(True)
+    tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(yn, S.dev), np.arange(B))
+    l = dec.fused_loss(hd, None, tiles.lib.reshape(-1, 1) if sf else None, None if sf else ld, tiles, "zinb")
+    assert l is not None
+    l.backward()
+    close(l, lo, rtol=5e-5, atol=0, what="zinb loss")
+    pairs = [("dh", hd.grad, ref[0].grad), ("dW", dec.output_mean[0].weight.grad, ref[1].grad),
+             ("db", dec.output_mean[0].bias.grad, ref[2].grad), ("dWpi", dec.output_dropout.weight.grad, ref[3].grad),
+             ("dbpi", dec.output_dropout.bias.grad, ref[4].grad)]
+    if not sf:
+        pairs.append(("dlat", ld.grad, ref[5].grad))
+    for nm, a, r_ in pairs:
+        close(a, r_, rtol=5e-4, atol=5e-4 * float(r_.abs().max()), what=f"zinb {nm}")
+    # the generic path (forward() + raw_loss) gives the same value
+    with torch.no_grad():
+        outs = dec(hd, None, tiles.lib.reshape(-1, 1) if sf else None, None if sf else ld)
+        lg = S.pkg.loss.raw_loss(x=tiles.to_dense(), px_mu_rate=outs[2], px_theta=outs[1], px_mu_scale=outs[0],
+                                 px_pi=outs[3], likelihood="zinb")
+    close(lg, lo, rtol=5e-5, atol=0, what="zinb loss (generic path)")
 
 
 def test_ber_eval_mode_matches_train_loss(S):
