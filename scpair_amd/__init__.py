@@ -13,5 +13,6 @@ from .pairedVAE import VAE_DECODER, VAE_ENCODER  # noqa: F401
 from .sparse import BatchTiles, DeviceCSR  # noqa: F401
 from .ops import FusedAdamW, get_precision, set_precision  # noqa: F401
 from .evaluator import FOSCTTM, FOSFTTM  # noqa: F401
+from .data import check_distribution, merge_paired_data, split_data, training_split  # noqa: F401
 
 __version__ = "0.1.0"

@@ -143,3 +143,76 @@ def test_data_loader_builder_matches_reference(tag, cov):
         assert list(meta.index) == list(gold[f"{tag}/{split}_index"])
         assert [str(c) for c in meta.columns] == list(gold[f"{tag}/{split}_columns"])
     assert n_checked == len([k for k in gold.files if k.startswith(tag + "/") and not k.endswith(("_index", "_columns"))])
+
+
+def test_training_split_matches_reference():
+    """training_split / split_data (utils.py:369-408) against labels the reference produced on the same object."""
+    import warnings
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_split.npz"))
+    cases = {"plain": dict(fracs=[0.8, 0.1, 0.1], seed=0), "seed7": dict(fracs=[0.7, 0.2, 0.1], seed=7),
+             "notest": dict(fracs=[0.75, 0.25, 0.0], seed=1),
+             "grouped": dict(fracs=[0.6, 0.2, 0.2], seed=2, batch_key="labels"),
+             "grouped2": dict(fracs=[0.5, 0.25, 0.25], seed=5, batch_key=["labels"])}
+    for tag, kw in cases.items():
+        ad = U.make_mini_adata(seed=4, n=90)
+        ad.obs = ad.obs.drop(columns=["scPair_split"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = S.training_split(ad, **kw)
+        assert list(res.obs.index) == list(d[f"{tag}/index"])
+        assert list(res.obs["scPair_split"]) == list(d[f"{tag}/split"]), tag
+        assert list(ad.obs["scPair_split"]) == list(d[f"{tag}/split"])         # written in place too, as upstream
+    ad = U.make_mini_adata(seed=4, n=90)
+    names = list(ad.obs.index)
+    res = S.training_split(ad, pre_split=(names[:50], names[50:60], names[70:]))
+    assert list(res.obs["scPair_split"]) == list(d["pre/split"])
+    assert set(res.obs["scPair_split"][60:70]) == {"TBD"}
+    with pytest.raises(AssertionError):
+        S.training_split(ad, fracs=[0.5, 0.1, 0.1])
+
+
+def test_check_distribution_and_merge():
+    """check_distribution (utils.py:341-353) against the reference's binarised matrices; merge_paired_data on two
+    single-modality objects (the reference needs the anndata package for this one: parity unpinned, the expected
+    result is stated from anndata.concat's documented inner-join / merge='same' semantics)."""
+    import pandas as pd
+    import scipy.sparse as sp
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_split.npz"))
+    for tag, sparse in (("sparse", True), ("dense", False)):
+        ad = U.make_mini_adata(seed=5, n=30, sparse=sparse)
+        S.check_distribution("Peaks", ad, "ber")
+        assert sp.issparse(ad.X) == sparse                               # stays sparse
+        X = ad.X.toarray() if sparse else np.asarray(ad.X)
+        assert np.array_equal(X.astype(np.int64), d[f"ber_{tag}/X"])
+    neg = U.make_mini_adata(seed=5, n=10, sparse=False); neg.X = neg.X - 1.0
+    with pytest.raises(ValueError):
+        S.check_distribution("Gene Expression", neg, "zinb")
+    pos = U.make_mini_adata(seed=5, n=10, sparse=False); pos.X = pos.X + 1.0
+    with pytest.raises(ValueError):
+        S.check_distribution("x", pos, "gau")
+    with pytest.warns(UserWarning):
+        S.check_distribution("Gene Expression", U.make_mini_adata(seed=5, n=10), "nb")
+    # merge: RNA counts + ATAC counts (binarised by the check), one cell missing from the second object
+    rng = np.random.default_rng(0)
+    n, g, p = 12, 5, 7
+    cells = [f"c{i}" for i in range(n)]
+    rna = U.MiniAnnData(sp.csr_matrix(rng.poisson(1.0, (n, g)).astype(np.float32)),
+                        pd.DataFrame({"donor": ["a", "b"] * 6, "qc": np.arange(n)}, index=cells),
+                        pd.DataFrame({"chrom": ["1"] * g}, index=[f"g{i}" for i in range(g)]))
+    keep = [i for i in range(n) if i != 3]
+    atac_counts = rng.poisson(0.4, (n, p)).astype(np.float32)
+    atac = U.MiniAnnData(sp.csr_matrix(atac_counts[keep]),
+                         pd.DataFrame({"donor": (["a", "b"] * 6)[:3] + (["a", "b"] * 6)[4:], "qc": np.arange(11) * 2},
+                                      index=[cells[i] for i in keep]),
+                         pd.DataFrame({"chrom": ["2"] * p, "width": 500}, index=[f"p{i}" for i in range(p)]))
+    rna_X = rna.X.toarray()
+    with pytest.warns(UserWarning):
+        m = S.merge_paired_data([rna, atac], ["Gene Expression", "Peaks"], ["zinb", "ber"])
+    assert sp.issparse(m.X) and m.X.shape == (n - 1, g + p)
+    assert list(m.obs.index) == [cells[i] for i in keep]
+    assert list(m.obs.columns) == ["donor"]                              # 'qc' differs between the two objects
+    assert list(m.var["modality"]) == ["Gene Expression"] * g + ["Peaks"] * p
+    assert list(m.var["modality_distribution"]) == ["zinb"] * g + ["ber"] * p
+    assert list(m.var.columns) == ["chrom", "modality", "modality_distribution"]
+    M = m.X.toarray()
+    assert np.array_equal(M[:, :g], rna_X[keep]) and np.array_equal(M[:, g:], (atac_counts[keep] > 0))
