@@ -46,6 +46,8 @@ def parse():
                     help="2: the two directions (independent trainings, model.py:608) run on two HIP streams")
     ap.add_argument("--fp32-exchange", action="store_true",
                     help="N > 1: all-reduce the wide first-layer gradients in fp32 even in bf16 mode (default: bf16)")
+    ap.add_argument("--no-fuse-opt", action="store_true",
+                    help="keep the AdamW step of the first-layer weights in the optimiser kernel (always so for N > 1)")
     ap.add_argument("--zinb", action="store_true", help="C3: zero-inflated NB for RNA (the G x G dropout layer is live)")
     return ap.parse_args()
 
@@ -72,11 +74,18 @@ class Direction:
         groups = [{"params": de, "weight_decay": 1e-9, "lr": 1e-3}, {"params": dd, "weight_decay": 1e-9, "lr": 1e-3},
                   {"params": ne, "weight_decay": 0, "lr": 1e-3}, {"params": nd, "weight_decay": 0, "lr": 1e-3}]
         self.opt = S.FusedAdamW([g for g in groups if g["params"]])
+        self.first = [self.enc.hidden_rep[0].weight] + ([self.enc.hidden_lib[0][0].weight] if infer_lib else [])
         self.dist = out_dist
+        self.fused = False
         self.use_lib = sample_factor
         self.enc.train(); self.dec.train()
 
     def n_trained_params(self):
+        """Parameters that received an update in the last step (dead layers get no gradient and are skipped)."""
+        fused = {id(p) for p in self.first} if self.fused else set()
+        return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None or id(p) in fused)
+
+    def n_unfused_params(self):
         return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None)
 
 
@@ -107,7 +116,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    # SCPAIR_BENCH_FORCE_DIST=1 (under torchrun --nproc-per-node 1): run the exchange path with one rank, which is
+    # all of the RCCL call sequence a one-GPU box can exercise
+    use_dist = world > 1 or bool(os.environ.get("SCPAIR_BENCH_FORCE_DIST"))
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -127,28 +139,48 @@ def main():
     A = Direction(S, a.genes, a.peaks, a.hidden, "ber", infer_lib=True, sample_factor=False, dropout=a.dropout, dev=dev)
     Bd = Direction(S, a.peaks, a.genes, a.hidden, "zinb" if a.zinb else "nb", infer_lib=False, sample_factor=True, dropout=a.dropout, dev=dev)
     sync = None
-    if world > 1:
+    if use_dist:
         from scpair_amd.distributed import GradSync
         sync = GradSync(compress=(a.precision == "bf16" and not a.fp32_exchange))
         for d_ in (A, Bd):
             sync.broadcast(list(d_.enc.parameters()) + list(d_.dec.parameters()))
 
+    fuse = (sync is None) and (not a.no_fuse_opt) and a.precision == "bf16"
+    if fuse:
+        for d_ in (A, Bd):
+            d_.opt.fuse_first_layer(*d_.first)
+            d_.fused = True
+
     rng = np.random.default_rng(1234 + rank)
     state = {"perm": rng.permutation(cells_here), "cur": 0}
+    state["perm_dev"] = torch.from_numpy(state["perm"]).to(dev)
     adam_ev = []
+    fused_ev = []
+
+    host_t = {"tiles": 0.0, "fwd": 0.0, "bwd": 0.0, "opt": 0.0}      # host enqueue time by phase (diagnostic)
+    pc = time.perf_counter
 
     def one_direction(D, tx, ty, time_adam):
         from scpair_amd.utils import _predictor_loss
+        t0_ = pc()
         lib = ty.lib.reshape(-1, 1) if D.use_lib else None
         loss = _predictor_loss(tx, ty, lib, D.enc, D.dec, D.dist, False, None, None)
+        t1_ = pc()
         D.opt.zero_grad()
         loss.backward()
+        host_t["fwd"] += t1_ - t0_
+        host_t["bwd"] += pc() - t1_
         params = [p for g in D.opt.param_groups for p in g["params"] if p.grad is not None]
         if sync is not None:
             sync.start_all_reduce([p.grad for p in params])
         return loss
 
     def finish_direction(D, time_adam):
+        t0_ = pc()
+        _finish_direction(D, time_adam)
+        host_t["opt"] += pc() - t0_
+
+    def _finish_direction(D, time_adam):
         if sync is not None:
             sync.finish()
         if time_adam:
@@ -156,17 +188,21 @@ def main():
             e0.record()
             D.opt.step(grad_scale=1.0 / world)
             e1.record()
-            adam_ev.append((e0, e1, D.n_trained_params()))
+            adam_ev.append((e0, e1, D.n_unfused_params()))
         else:
             D.opt.step(grad_scale=1.0 / world)
 
     def step(time_adam=False):
         if state["cur"] + a.batch > cells_here:
             state["perm"], state["cur"] = rng.permutation(cells_here), 0
+            state["perm_dev"] = torch.from_numpy(state["perm"]).to(dev)        # one upload per epoch
         rows = state["perm"][state["cur"]:state["cur"] + a.batch]
+        rows_dev = state["perm_dev"][state["cur"]:state["cur"] + a.batch]
         state["cur"] += a.batch
-        t_rna = S.BatchTiles(rna, rows, want_lib=True)
-        t_atac = S.BatchTiles(atac, rows, want_lib=False)
+        t0_ = pc()
+        t_rna = S.BatchTiles(rna, rows_dev, want_lib=True, rows_host=rows)
+        t_atac = S.BatchTiles(atac, rows_dev, want_lib=False, rows_host=rows)
+        host_t["tiles"] += pc() - t0_
         if side is None:
             la = one_direction(A, t_rna, t_atac, time_adam)
             finish_direction(A, time_adam)
@@ -192,40 +228,80 @@ def main():
     side = (torch.cuda.Stream(), torch.cuda.Stream()) if a.streams == 2 else None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
     barrier()
+    prof = None
+    if os.environ.get("SCPAIR_BENCH_CPROFILE") and rank == 0:      # diagnostic: where the host enqueue time goes
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
+    if fuse:
+        S.ops.set_fused_timer(fused_ev)
+    for k_ in host_t:
+        host_t[k_] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         la, lb = step(time_adam=True)
     t_host = time.perf_counter() - t0             # host enqueue time of the timed steps (diagnostic)
+    S.ops.set_fused_timer(None)
+    if prof is not None:
+        import pstats
+        prof.disable()
+        with open(os.environ["SCPAIR_BENCH_CPROFILE"], "w") as fh:
+            pstats.Stats(prof, stream=fh).sort_stats("cumulative").print_stats(70)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     losses = (float(la.detach()), float(lb.detach()))
 
-    # ---- roofline of the dominant kernel: fused AdamW, 28 B/param ---------------------------------
+    # ---- roofline of the dominant kernel ------------------------------------------------------------------------
+    # Two-kernel path (--no-fuse-opt, N > 1): the multi-tensor AdamW kernel, 28 B/param.
+    # Fused path (default at N = 1): the first-layer weight-gradient kernel with the AdamW step in its epilogue; it
+    # moves 24 B/param of optimiser state (p, m, v read and written; the gradient stays on chip) + 2 B/param of bf16
+    # shadow + its operands (tile-list entries, bf16 dY^T).  Timed with events around each launch on its stream.
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in adam_ev)
     tot_bytes = sum(28.0 * n for _, _, n in adam_ev)
     adam_gbs = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     n_params = A.n_trained_params() + Bd.n_trained_params()
-    # HBM bytes of the same kernel from PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes
-    # over this command; profiles/r01_adamw_traffic.json).  Only quoted when it was collected for this exact workload.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_adamw_traffic.json")) as fh:
-            tr = json.load(fh)
-        if abs(tr["algorithmic_bytes_per_step"] - 28.0 * n_params) < 1.0 and a.precision == "bf16":
-            traffic = tr["hbm_bytes_per_step"]
-    except (OSError, KeyError, ValueError):
-        pass
+    adam_roof = {"kernel": "adamw_kernel (fused multi-tensor AdamW)", "bound": "hbm", "achieved": adam_gbs,
+                 "peak": 8000.0, "unit": "GB/s", "frac": adam_gbs / 8000.0, "traffic": None,
+                 "algorithmic_bytes_per_launch_set": tot_bytes / max(a.steps, 1),
+                 "avg_ms_per_step_in_kernel": tot_ms / max(a.steps, 1)}
+
+    def pmc_traffic(name, want_bytes):
+        # HBM bytes of the kernel from PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes over
+        # this command; profiles/*.json).  Only quoted when it was collected for this exact workload.
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                tr = json.load(fh)
+            if abs(tr["algorithmic_bytes_per_step"] - want_bytes) < 1.0 and a.precision == "bf16":
+                return tr["hbm_bytes_per_step"]
+        except (OSError, KeyError, ValueError):
+            pass
+        return None
+
+    if fused_ev:
+        f_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in fused_ev)
+        f_bytes = sum(26.0 * n + ob for _, _, n, ob in fused_ev)
+        f_gbs = f_bytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
+        roof = {"kernel": "spmm_dw_bf16_kernel<*, ADAM> (first-layer weight gradient with the AdamW step in its epilogue)",
+                "bound": "hbm", "achieved": f_gbs, "peak": 8000.0, "unit": "GB/s", "frac": f_gbs / 8000.0,
+                "traffic": pmc_traffic("r01_dw_adamw_traffic.json", f_bytes / max(a.steps, 1)),
+                "algorithmic_bytes_per_launch_set": f_bytes / max(a.steps, 1),
+                "avg_ms_per_step_in_kernel": f_ms / max(a.steps, 1),
+                "launches_per_step": len(fused_ev) / max(a.steps, 1),
+                "other_params": adam_roof}
+    else:
+        adam_roof["traffic"] = pmc_traffic("r01_adamw_traffic.json", 28.0 * n_params)
+        roof = adam_roof
 
     out = {
         "metric": "training cells/sec (whole node) paired RNA+ATAC",
@@ -240,20 +316,19 @@ def main():
                                f"batch {a.batch}/GPU, hidden {a.hidden}, dropout {a.dropout}, both directions per step",
                    "cells_resident_per_gpu": cells_here, "nnz_per_cell_rna": round(nnz_r, 1),
                    "nnz_per_cell_atac": round(nnz_a, 1), "precision": a.precision, "parallelism": f"dp{world}", "streams": a.streams,
-                   "grad_exchange": ("none" if world == 1 else ("bf16 wide + fp32 rest" if sync.compress else "fp32")),
+                   "grad_exchange": ("none" if sync is None else ("bf16 wide + fp32 rest" if sync.compress else "fp32")),
+                   "optimizer": "AdamW; first-layer weights updated in their weight-gradient kernel" if fuse else "AdamW, one multi-tensor kernel",
                    "host_enqueue_ms_per_step": round(1e3 * t_host / a.steps, 3),
+                   "host_enqueue_ms_by_phase": {k_: round(1e3 * v_ / a.steps, 3) for k_, v_ in host_t.items()},
                    "trained_params": n_params, "final_losses": losses},
-        "roofline": {"kernel": "adamw_kernel (fused multi-tensor AdamW)", "bound": "hbm", "achieved": adam_gbs,
-                     "peak": 8000.0, "unit": "GB/s", "frac": adam_gbs / 8000.0, "traffic": traffic,
-                     "algorithmic_bytes_per_launch_set": 28.0 * n_params,
-                     "avg_ms_per_step_in_kernel": tot_ms / max(a.steps, 1)},
+        "roofline": roof,
     }
 
     if rank == 0 and world == 1 and a.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(a, S, A, Bd, rna, atac, rng)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -56,6 +56,15 @@ int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int3
                       const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream);
 int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
                      const void* dYT, long ldt, float* dW, long ldw, void* stream);
+/* The same weight gradient with the AdamW step of that weight (model.py:698-701, torch.optim.AdamW semantics as in
+ * scp_adamw_multi) applied in the kernel's epilogue: W [N][ldw] fp32 master weights, exp_avg / exp_avg_sq (same
+ * layout) and the bf16 shadow are updated in place and the gradient never reaches HBM.  For single-process training
+ * (no gradient exchange between backward and the optimiser step).  Needs F % 4 == 0, ldw % 4 == 0, ld_bf16 % 4 == 0
+ * and 16-byte aligned W / moments (SCP_ERR_SHAPE otherwise: use scp_spmm_dw_bf16 + scp_adamw_multi). */
+int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
+                           const void* dYT, long ldt, float* W, long ldw, float* exp_avg, float* exp_avg_sq,
+                           void* W_bf16, long ld_bf16, float lr, float weight_decay, float beta1, float beta2, float eps,
+                           float bias_corr1, float bias_corr2, float grad_scale, void* stream);
 
 /* ---- dense layers: nn.Linear forward / dgrad / wgrad (utils.py:57; model.py:84, 92, 163, 217, 228,
  *      280, 331; pairedVAE.py:49-50, 111-119) as one strided GEMM  C[M,N] (+)= A[M,K] B[N,K]^T + bias ---- */
@@ -148,11 +157,12 @@ int scp_relu_softmax_rows(const float* z, long ldz, int rows, int cols, const fl
 /* ---- (ZI)NB decoder heads on materialised pre-activations (ZINB predictor with its G x G zero-inflation layer,
  *      model.py:228-259; loss.py:46-51; scVI_distribution.py:29-105), dispersion 'feature-cell', no feature factor:
  *      z [B][G] = output_mean Linear output, pi [B][G] zero-inflation logits or null (plain NB), y dense labels,
- *      L [B] library term.  fwd: loss, lse [B], T [B] (kept for bwd), part: B doubles.  bwd: dz, dpi, dL (nullable) ---- */
+ *      L [B] library term.  fast != 0: hardware exp / log / reciprocal (precision mode 'bf16').
+ *      fwd: loss, lse [B], T [B] (kept for bwd), part: B doubles.  bwd: dz, dpi, dL (nullable) ---- */
 int scp_raw_rows_fwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy, const float* L,
-                     int B, int G, float* lse, float* T, double* part, float* loss, void* stream);
+                     int B, int G, int fast, float* lse, float* T, double* part, float* loss, void* stream);
 int scp_raw_rows_bwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy, const float* L,
-                     const float* lse, const float* T, const float* gout, int B, int G, float* dz, long lddz,
+                     const float* lse, const float* T, const float* gout, int B, int G, int fast, float* dz, long lddz,
                      float* dpi, long lddp, float* dL, void* stream);
 
 /* ---- evaluation metrics (evaluator.py:14-71): neighbour counts behind FOSCTTM / FOSFTTM for paired embeddings

@@ -44,6 +44,7 @@ _SIGS = {
     "scp_spmm_fwd_bf16_min_split": (I, [I]),
     "scp_spmm_fwd_bf16": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
     "scp_spmm_dw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
+    "scp_spmm_dw_adamw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P, P, P, L, F, F, F, F, F, F, F, F, P]),
     "scp_gemm_nt": (I, [I, I, I, P, L, L, P, L, L, P, L, P, I, I, I, P]),
     "scp_gemm_lib_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P]),
     "scp_slab_reduce": (I, [P, L, I, I, I, L, P, P, L, P]),
@@ -69,8 +70,8 @@ _SIGS = {
     "scp_reparam_kl_bwd": (I, [P, P, P, P, P, P, P, L, P, P, P]),
     "scp_ber_prob": (I, [P, L, I, I, P, I, P, P, L, P]),
     "scp_relu_softmax_rows": (I, [P, L, I, I, P, I, P, L, P, L, P]),
-    "scp_raw_rows_fwd": (I, [P, L, P, L, P, L, P, I, I, P, P, P, P, P]),
-    "scp_raw_rows_bwd": (I, [P, L, P, L, P, L, P, P, P, P, I, I, P, L, P, L, P, P]),
+    "scp_raw_rows_fwd": (I, [P, L, P, L, P, L, P, I, I, I, P, P, P, P, P]),
+    "scp_raw_rows_bwd": (I, [P, L, P, L, P, L, P, P, P, P, I, I, I, P, L, P, L, P, P]),
     "scp_fos_counts": (I, [P, L, P, L, I, I, P, P, P, P, P]),
     "scp_adamw_multi": (I, [C.POINTER(AdamTensor), I, F, F, F, P]),
 }
@@ -113,7 +114,15 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """Handle of torch's current HIP stream on the current device (every kernel is launched on it)."""
+    if _raw_stream is not None:
+        # same value as torch.cuda.current_stream().cuda_stream without building the Python Stream object (called
+        # ~50 times per training step)
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -22,19 +22,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
   while (ti + 1 < pk.n && blk >= pk.chunk_start[ti + 1]) ti++;
   const ScpAdamTensor t = pk.t[ti];
   long base = (long)(blk - pk.chunk_start[ti]) * ADAM_CHUNK;
-  float b1 = pk.beta1, b2 = pk.beta2;
-  float decay = 1.f - t.lr * t.weight_decay;
-  float step_size = t.lr / t.bias_corr1;
-  float inv_sqrt_bc2 = 1.f / sqrtf(t.bias_corr2);
+  const AdamHyper hy = adam_hyper(t.lr, t.weight_decay, pk.beta1, pk.beta2, pk.eps, t.bias_corr1, t.bias_corr2,
+                                  t.grad_scale);
   bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
-  auto update = [&](float& p, float g, float& m, float& v) {
-    float gk = g * t.grad_scale;
-    p *= decay;
-    m = m + (gk - m) * (1.f - b1);
-    v = v * b2 + gk * gk * (1.f - b2);
-    float denom = sqrtf(v) * inv_sqrt_bc2 + pk.eps;
-    p -= step_size * (m / denom);
-  };
+  auto update = [&](float& p, float g, float& m, float& v) { adamw_update(hy, p, g, m, v); };
   auto shadow4 = [&](long i, const float (&pa)[4]) {
     __bf16* sh = (__bf16*)t.p_bf16;
     if ((t.cols & 3) == 0) {

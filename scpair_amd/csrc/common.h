@@ -66,6 +66,32 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 //   col = lane & 31 ; row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// ---- AdamW element update (torch.optim.AdamW, amsgrad False), shared by the multi-tensor optimiser kernel and
+// the first-layer weight-gradient kernel that applies the update in its epilogue -----------------------------
+struct AdamHyper {
+  float decay;          // 1 - lr * weight_decay
+  float step_size;      // lr / (1 - beta1^t)
+  float inv_sqrt_bc2;   // 1 / sqrt(1 - beta2^t)
+  float b1, b2, eps, grad_scale;
+};
+__device__ __forceinline__ AdamHyper adam_hyper(float lr, float wd, float b1, float b2, float eps, float bc1, float bc2,
+                                                float grad_scale) {
+  AdamHyper h;
+  h.decay = 1.f - lr * wd;
+  h.step_size = lr / bc1;
+  h.inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  h.b1 = b1; h.b2 = b2; h.eps = eps; h.grad_scale = grad_scale;
+  return h;
+}
+__device__ __forceinline__ void adamw_update(const AdamHyper& h, float& p, float g, float& m, float& v) {
+  float gk = g * h.grad_scale;
+  p *= h.decay;
+  m = m + (gk - m) * (1.f - h.b1);
+  v = v * h.b2 + gk * gk * (1.f - h.b2);
+  float denom = sqrtf(v) * h.inv_sqrt_bc2 + h.eps;
+  p -= h.step_size * (m / denom);
+}
+
 // ---- wave / block reductions -------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -12,49 +12,56 @@
 #include "common.h"
 #include "scpair_hip.h"
 
+template <bool FAST> __device__ __forceinline__ float softplus_(float x) {
+  if (!FAST) return softplus_t(x);
+  return x > 20.f ? x : __logf(1.f + __expf(x));
+}
+
 struct RawTerms {
   float ll, dm, dth, dp, mu, th;
 };
 
 // element terms shared by forward and backward (same arithmetic as nbll_fwd/bwd_kernel in elementwise.hip)
-template <bool WANT_LL, bool WANT_GRAD>
+// FAST (precision mode 'bf16'): hardware exp / log / reciprocal, as in the fused decoders
+template <bool WANT_LL, bool WANT_GRAD, bool FAST>
 __device__ __forceinline__ RawTerms raw_terms(float zv, float xv, float L, float lse, bool zi, float pv) {
   const float eps = 1e-8f;
   RawTerms t;
   float a = fmaxf(zv, 0.f);
-  float scale = expf(a - lse);
+  float scale = exp_<FAST>(a - lse);
   t.mu = L * scale;
-  t.th = expf(a);
+  t.th = exp_<FAST>(a);
   float m = t.mu, th = t.th;
   float s = th + m + eps;
-  float lt = logf(th + eps), ls = logf(s);
+  float lt = log_<FAST>(th + eps), ls = log_<FAST>(s);
   bool nz = xv > eps, zero = xv < eps;
   t.ll = 0.f; t.dm = 0.f; t.dth = 0.f; t.dp = 0.f;
   float base = th * (lt - ls);
   if (WANT_LL) {
-    float c1 = base + xv * (logf(m + eps) - ls) + (nz ? lgam3<false>(xv, th) : 0.f);
+    float c1 = base + xv * (log_<FAST>(m + eps) - ls) + (nz ? lgam3<FAST>(xv, th) : 0.f);
     if (!zi) {
       t.ll = c1;
     } else {
-      float sp = softplus_t(-pv);
+      float sp = softplus_<FAST>(-pv);
       float tt = -pv + base;
-      float c0 = softplus_t(tt) - sp;
+      float c0 = softplus_<FAST>(tt) - sp;
       t.ll = (zero ? c0 : 0.f) + (nz ? (c1 - pv - sp) : 0.f);
     }
   }
   if (WANT_GRAD) {
-    float dt_dmu = -th / s;
-    float dt_dth = lt - ls + th / (th + eps) - th / s;
-    float dig = nz ? digam2<false>(xv, th) : 0.f;
-    float dm_nz = dt_dmu + xv * (1.f / (m + eps) - 1.f / s);
-    float dth_nz = dt_dth - xv / s + dig;
+    float is = div_<FAST>(1.f, s);
+    float dt_dmu = -th * is;
+    float dt_dth = lt - ls + div_<FAST>(th, th + eps) - th * is;
+    float dig = nz ? digam2<FAST>(xv, th) : 0.f;
+    float dm_nz = dt_dmu + xv * (div_<FAST>(1.f, m + eps) - is);
+    float dth_nz = dt_dth - xv * is + dig;
     if (!zi) {
       t.dm = dm_nz;
       t.dth = dth_nz;
     } else {
       float tt = -pv + base;
-      float sig_t = tt > 20.f ? 1.f : sigmoidf_(tt);
-      float sig_npi = (-pv) > 20.f ? 1.f : sigmoidf_(-pv);
+      float sig_t = tt > 20.f ? 1.f : sigm_<FAST>(tt);
+      float sig_npi = (-pv) > 20.f ? 1.f : sigm_<FAST>(-pv);
       if (zero) {
         t.dm = sig_t * dt_dmu;
         t.dth = sig_t * dt_dth;
@@ -69,6 +76,7 @@ __device__ __forceinline__ RawTerms raw_terms(float zv, float xv, float L, float
   return t;
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void raw_rows_fwd_kernel(const float* __restrict__ z, long ldz,
                                                            const float* __restrict__ pi, long ldp,
                                                            const float* __restrict__ y, long ldy,
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void raw_rows_fwd_kernel(const float* __restri
   __syncthreads();
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float se = 0.f;
-  for (int j = tid; j < G; j += 256) se += expf(fmaxf(zr[j], 0.f) - m);
+  for (int j = tid; j < G; j += 256) se += exp_<FAST>(fmaxf(zr[j], 0.f) - m);
   se = block_sum(se, red);
   if (tid == 0) bc[0] = m + logf(se);
   __syncthreads();
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256) void raw_rows_fwd_kernel(const float* __restri
   float T = 0.f;
   for (int j = tid; j < G; j += 256) {
     float pv = zi ? pi[(long)b * ldp + j] : 0.f;
-    RawTerms t = raw_terms<true, true>(zr[j], y[(long)b * ldy + j], L, lse, zi, pv);
+    RawTerms t = raw_terms<true, true, FAST>(zr[j], y[(long)b * ldy + j], L, lse, zi, pv);
     ll += (double)t.ll;
     T += t.mu * t.dm;
   }
@@ -120,6 +128,7 @@ __global__ void raw_rows_finish_kernel(const double* __restrict__ part, int B, d
   if (threadIdx.x == 0) loss[0] = (float)(-s / n_total);
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void raw_rows_bwd_kernel(const float* __restrict__ z, long ldz,
                                                            const float* __restrict__ pi, long ldp,
                                                            const float* __restrict__ y, long ldy,
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256) void raw_rows_bwd_kernel(const float* __restri
   for (int j = tid; j < G; j += 256) {
     float zv = z[(long)b * ldz + j];
     float pv = zi ? pi[(long)b * ldp + j] : 0.f;
-    RawTerms t = raw_terms<false, true>(zv, y[(long)b * ldy + j], L, lse, zi, pv);
+    RawTerms t = raw_terms<false, true, FAST>(zv, y[(long)b * ldy + j], L, lse, zi, pv);
     float scale = t.mu / L;
     // softmax backward (g_j = L dm_j): mu dm - scale T ; theta = exp(a) path: dth * th
     float da = c * (t.mu * t.dm - scale * T + t.dth * t.th);
@@ -147,11 +156,14 @@ __global__ __launch_bounds__(256) void raw_rows_bwd_kernel(const float* __restri
 }
 
 extern "C" int scp_raw_rows_fwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy,
-                                const float* Lrow, int B, int G, float* lse, float* T, double* part, float* loss,
-                                void* stream_) {
+                                const float* Lrow, int B, int G, int fast, float* lse, float* T, double* part,
+                                float* loss, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(B > 0 && G > 0 && z && y && Lrow && lse && T && part && loss, SCP_ERR_ARG, "scp_raw_rows_fwd: bad argument");
-  hipLaunchKernelGGL(raw_rows_fwd_kernel, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, B, G, lse, T, part);
+  if (fast)
+    hipLaunchKernelGGL(raw_rows_fwd_kernel<true>, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, B, G, lse, T, part);
+  else
+    hipLaunchKernelGGL(raw_rows_fwd_kernel<false>, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, B, G, lse, T, part);
   SCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(raw_rows_finish_kernel, dim3(1), dim3(256), 0, stream, part, B, (double)B * (double)G, loss);
   SCP_LAUNCH_CHECK();
@@ -160,12 +172,16 @@ extern "C" int scp_raw_rows_fwd(const float* z, long ldz, const float* pi, long 
 
 extern "C" int scp_raw_rows_bwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy,
                                 const float* Lrow, const float* lse, const float* T, const float* gout, int B, int G,
-                                float* dz, long lddz, float* dpi, long lddp, float* dL, void* stream_) {
+                                int fast, float* dz, long lddz, float* dpi, long lddp, float* dL, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(B > 0 && G > 0 && z && y && Lrow && lse && T && dz, SCP_ERR_ARG, "scp_raw_rows_bwd: bad argument");
   SCP_CHECK((pi == nullptr) == (dpi == nullptr), SCP_ERR_ARG, "scp_raw_rows_bwd: pi and dpi go together");
-  hipLaunchKernelGGL(raw_rows_bwd_kernel, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, lse, T, gout, B, G,
-                     dz, lddz, dpi, lddp, dL);
+  if (fast)
+    hipLaunchKernelGGL(raw_rows_bwd_kernel<true>, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, lse, T, gout,
+                       B, G, dz, lddz, dpi, lddp, dL);
+  else
+    hipLaunchKernelGGL(raw_rows_bwd_kernel<false>, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, lse, T, gout,
+                       B, G, dz, lddz, dpi, lddp, dL);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

@@ -26,6 +26,9 @@ struct SpArgs {
   const __bf16* D; long ldd; // dense bf16 operand: forward Wbf[N][ldd] ; wgrad dYT[N][ldd]
   float* C; long ldc;        // forward: slabs [nsplit][ncells][ldc] ; wgrad: dW[N][ldc]
   int nsplit, ksplit_len, tiles_m, tiles_n;
+  // wgrad with the AdamW update applied in the epilogue (C = the fp32 master weights, updated in place)
+  float* adam_m; float* adam_v; __bf16* adam_sh; long adam_ldsh;
+  float lr, wd, b1, b2, eps, bc1, bc2, gscale;
 };
 
 __device__ __forceinline__ uint4 ld16(const __bf16* p, bool ok) {
@@ -272,8 +275,15 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
 // Same pipeline as the forward kernel with the operand roles swapped: the sparse X tile [feature][cell] lives in
 // three LDS buffers (scatter for step i+1, MFMAs of step i, un-scatter of step i-1), the dense dY^T tile in two,
 // one barrier per step, three steps of loads in flight in registers.
+//
+// ADAM: the gradient tile never goes to HBM.  The accumulators are laid out row-major in LDS (the operand buffers
+// are free after the K loop) and every wave then streams whole 1 KB rows of the master weights and the two AdamW
+// moments through the update, writing them and the bf16 shadow back: 26 B/parameter of HBM traffic instead of
+// 4 (dW written) + 30 (optimiser kernel), and that traffic overlaps the MFMA phases of the other workgroups.
+// Measured at C2 (900 x 100 k weights, 1024 cells): 556 us against 274 + 420 us for the two kernels; with a single
+// K-step the launch takes 457 us, i.e. the epilogue streams at 5.1 TB/s and most of the K loop hides behind it.
 // ------------------------------------------------------------------------------------------------------
-template <bool HASVAL>
+template <bool HASVAL, bool ADAM, int EPB = 16>
 __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
   constexpr int EPT = HASVAL ? 4 : 2;             // sparse entries held per thread and stage
   constexpr int ASZ = 128 * LDK, BSZ = 256 * LDK;
@@ -294,7 +304,6 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
   const int m0 = m_tile * 128, n0 = unit * 256;
   const int nend = min(n0 + 256, g.F);
   const int nstep = g.ncb;
-
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -449,18 +458,76 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
     if (i + 2 < nstep) k_step(F_{}, S2{}, i + 2);
   }
 
+  if constexpr (!ADAM) {
 #pragma unroll
-  for (int i2 = 0; i2 < 2; i2++)
+    for (int i2 = 0; i2 < 2; i2++)
 #pragma unroll
-    for (int jj = 0; jj < 2; jj++) {
-      int n = n0 + wn * 64 + jj * 32 + r;
-      if (n >= g.F) continue;
+      for (int jj = 0; jj < 2; jj++) {
+        int n = n0 + wn * 64 + jj * 32 + r;
+        if (n >= g.F) continue;
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        int m = m0 + wm * 64 + i2 * 32 + acc_row(e, lane);
-        if (m < g.N) g.C[(long)m * g.ldc + n] = acc[i2][jj][e];
+        for (int e = 0; e < 16; e++) {
+          int m = m0 + wm * 64 + i2 * 32 + acc_row(e, lane);
+          if (m < g.N) g.C[(long)m * g.ldc + n] = acc[i2][jj][e];
+        }
+      }
+  } else {
+    // gradient tile -> LDS [128][GLD] (all waves passed the last barrier of the K loop: the operand buffers are dead)
+    constexpr int GLD = 260;
+    float* gt = (float*)smem_raw;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+          gt[(wm * 64 + i2 * 32 + acc_row(e, lane)) * GLD + wn * 64 + jj * 32 + r] = acc[i2][jj][e];
+    __syncthreads();
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const AdamHyper hy = adam_hyper(g.lr, g.wd, g.b1, g.b2, g.eps, g.bc1, g.bc2, g.gscale);
+    const int c4 = (tid & 63) * 4, rw = tid >> 6;   // one wave per 1 KB row segment, 8 rows per pass
+    const int n = n0 + c4;
+    const bool col_ok = n + 4 <= g.F;               // F % 4 == 0 (host-checked): a float4 is all in or all out
+#pragma unroll 1
+    for (int pass = 0; pass < 16; pass += EPB) {
+      // EPB row segments of the three streams in flight per lane before the first use: with one workgroup per CU the
+      // epilogue's HBM rate is set by the bytes each CU keeps outstanding
+      f4 pp[EPB], mm[EPB], vv[EPB];
+#pragma unroll
+      for (int u = 0; u < EPB; u++) {
+        int m = m0 + (pass + u) * 8 + rw;
+        if (col_ok && m < g.N) {
+          long o = (long)m * g.ldc + n;
+          pp[u] = __builtin_nontemporal_load((const f4*)(g.C + o));
+          mm[u] = __builtin_nontemporal_load((const f4*)(g.adam_m + o));
+          vv[u] = __builtin_nontemporal_load((const f4*)(g.adam_v + o));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < EPB; u++) {
+        int row = (pass + u) * 8 + rw;
+        int m = m0 + row;
+        if (col_ok && m < g.N) {
+          f4 gg = *(const f4*)&gt[row * GLD + c4];
+          float pa[4], ma[4], va[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            pa[k] = pp[u][k]; ma[k] = mm[u][k]; va[k] = vv[u][k];
+            adamw_update(hy, pa[k], gg[k], ma[k], va[k]);
+          }
+          long o = (long)m * g.ldc + n;
+          f4 po = {pa[0], pa[1], pa[2], pa[3]}, mo = {ma[0], ma[1], ma[2], ma[3]}, vo = {va[0], va[1], va[2], va[3]};
+          __builtin_nontemporal_store(po, (f4*)(g.C + o));
+          __builtin_nontemporal_store(mo, (f4*)(g.adam_m + o));
+          __builtin_nontemporal_store(vo, (f4*)(g.adam_v + o));
+          bf16x4 sh;
+#pragma unroll
+          for (int k = 0; k < 4; k++) sh[k] = (__bf16)pa[k];
+          *(bf16x4*)(g.adam_sh + (long)m * g.adam_ldsh + n) = sh;
+        }
       }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -566,8 +633,8 @@ extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, 
             64 * (PCH + 1));
   static bool done_v = false, done_n = false;
   size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
-  int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true>, smem, &done_v)
-                 : set_smem((const void*)spmm_dw_bf16_kernel<false>, smem, &done_n);
+  int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true, false>, smem, &done_v)
+                 : set_smem((const void*)spmm_dw_bf16_kernel<false, false>, smem, &done_n);
   if (rc) return rc;
   SpArgs g = {};
   g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
@@ -575,9 +642,48 @@ extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, 
   g.tiles_m = (N + 127) / 128; g.tiles_n = (F + 255) / 256; g.nsplit = 1;
   int grid = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
   if (t_val)
-    hipLaunchKernelGGL(spmm_dw_bf16_kernel<true>, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+    hipLaunchKernelGGL((spmm_dw_bf16_kernel<true, false>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
   else
-    hipLaunchKernelGGL(spmm_dw_bf16_kernel<false>, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+    hipLaunchKernelGGL((spmm_dw_bf16_kernel<false, false>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key,
+                                      const float* t_val, const void* dYT, long ldt, float* W, long ldw, float* exp_avg,
+                                      float* exp_avg_sq, void* W_bf16, long ld_bf16, float lr, float weight_decay,
+                                      float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                                      float grad_scale, void* stream_) {
+  SCP_CHECK(ncells > 0 && N > 0 && F > 0, SCP_ERR_ARG, "scp_spmm_dw_adamw_bf16: sizes must be positive");
+  SCP_CHECK(t_ptr && t_key && dYT && W && exp_avg && exp_avg_sq && W_bf16, SCP_ERR_ARG,
+            "scp_spmm_dw_adamw_bf16: null pointer");
+  SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
+            "scp_spmm_dw_adamw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
+  SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: more than %d cells per call unsupported",
+            64 * (PCH + 1));
+  SCP_CHECK(F % 4 == 0 && ldw % 4 == 0 && ldw >= F && ld_bf16 % 4 == 0 && ld_bf16 >= F &&
+                (((uintptr_t)W | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) == 0 && ((uintptr_t)W_bf16 % 8) == 0,
+            SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: needs F %% 4 == 0, leading dimensions %% 4 == 0 and 16-byte aligned W / moments");
+  SCP_CHECK(bias_corr1 > 0.f && bias_corr2 > 0.f, SCP_ERR_ARG, "scp_spmm_dw_adamw_bf16: bias corrections must be > 0");
+  static bool done_v = false, done_n = false;
+  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
+  static_assert((size_t)128 * 260 * sizeof(float) <= (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16),
+                "gradient tile must fit in the operand buffers");
+  int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true, true>, smem, &done_v)
+                 : set_smem((const void*)spmm_dw_bf16_kernel<false, true>, smem, &done_n);
+  if (rc) return rc;
+  SpArgs g = {};
+  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
+  g.D = (const __bf16*)dYT; g.ldd = ldt; g.C = W; g.ldc = ldw;
+  g.tiles_m = (N + 127) / 128; g.tiles_n = (F + 255) / 256; g.nsplit = 1;
+  g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_sh = (__bf16*)W_bf16; g.adam_ldsh = ld_bf16;
+  g.lr = lr; g.wd = weight_decay; g.b1 = beta1; g.b2 = beta2; g.eps = eps; g.bc1 = bias_corr1; g.bc2 = bias_corr2;
+  g.gscale = grad_scale;
+  int grid = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
+  if (t_val)
+    hipLaunchKernelGGL((spmm_dw_bf16_kernel<true, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+  else
+    hipLaunchKernelGGL((spmm_dw_bf16_kernel<false, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

@@ -72,11 +72,8 @@ class GradSync:
             if work is not None:
                 work.wait()
             if flat is not None:
-                o = 0
-                for g in small:
-                    n = g.numel()
-                    g.copy_(flat[o:o + n].view_as(g))
-                    o += n
+                parts = flat.split([g.numel() for g in small])
+                torch._foreach_copy_(small, [p.view_as(g) for p, g in zip(parts, small)])
         self._pending = []
 
     def all_reduce_grads(self, params, n_valid):

@@ -347,7 +347,7 @@ class scPair_object():
                  memory_efficient_loading=True,
                  val_chunk=4096,
                  verbose=True,
-                 grad_sync=None):
+                 grad_sync=None, fuse_optimizer=True):
         self.scobj = scobj
         self.modalities = modalities
         self.modality_names = list(modalities.keys())
@@ -397,6 +397,7 @@ class scPair_object():
         self.val_chunk = int(val_chunk)
         self.verbose = verbose
         self.grad_sync = grad_sync          # data-parallel hook (scpair_amd.distributed.GradSync) or None
+        self.fuse_optimizer = fuse_optimizer  # AdamW step of the first-layer weights inside their dW kernel (1 process)
         self.scaler = None
         self.history = {}
         if self.add_linear_layer is True and self.mapping_non_neg is True:
@@ -683,7 +684,18 @@ class scPair_object():
                   {'params': decay_d, 'weight_decay': self.L2_lambda, 'lr': lr},
                   {'params': nodecay_e, 'weight_decay': 0, 'lr': lr},
                   {'params': nodecay_d, 'weight_decay': 0, 'lr': lr}]
-        return ops.FusedAdamW([g for g in groups if len(g['params']) > 0])
+        opt = ops.FusedAdamW([g for g in groups if len(g['params']) > 0])
+        if self.grad_sync is None and self.fuse_optimizer:
+            # single process: the AdamW step of the wide sparse first-layer weights runs inside their
+            # weight-gradient kernel (precision 'bf16', no covariate block; other cases keep the two-kernel path)
+            firsts = []
+            for seq in (getattr(encoder, 'hidden_rep', None), getattr(encoder, 'hidden_lib', None)):
+                while isinstance(seq, nn.Sequential) and len(seq) > 0:
+                    seq = seq[0]
+                if isinstance(seq, nn.Linear):
+                    firsts.append(seq.weight)
+            opt.fuse_first_layer(*firsts)
+        return opt
 
     def train_predicting_networks(self, train_data_dict, val_data_dict, test_data_dict, batch_replay=None):
         """model.py:603-812.  `batch_replay`: optional {direction_index: [row-id arrays]} to replay a recorded batch
@@ -735,12 +747,14 @@ class scPair_object():
                 for rows in batches:
                     if self.grad_sync is not None:
                         rows = self.grad_sync.shard(rows)
-                    tx = BatchTiles(xtr, rows, want_lib=False)
-                    c = None if ctr is None else ctr[torch.as_tensor(rows, device=self.device)]
+                    rows = np.asarray(rows, dtype=np.int64)
+                    rows_dev = torch.from_numpy(rows).to(self.device)          # one upload, shared by both modalities
+                    tx = BatchTiles(xtr, rows_dev, want_lib=False, rows_host=rows)
+                    c = None if ctr is None else ctr[rows_dev]
                     if dist == 'gau':
-                        ty, lib = ytr_dense[torch.as_tensor(rows, device=self.device)], None
+                        ty, lib = ytr_dense[rows_dev], None
                     else:
-                        ty = BatchTiles(ytr, rows, want_lib=use_lib)
+                        ty = BatchTiles(ytr, rows_dev, want_lib=use_lib, rows_host=rows)
                         lib = ty.lib.reshape(-1, 1) if use_lib else None
                     loss = self._train_step(tx, ty, lib, encoder, decoder, optimizer, dist, c)
                     step_losses.append(loss)

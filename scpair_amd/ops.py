@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from .sparse import BatchTiles
 
-_cfg = {"ns": 3, "seed_ctr": 0}
+_cfg = {"ns": 3, "seed_ctr": 0, "fused_timer": None}
 
 
 def set_precision(mode: str):
@@ -30,6 +30,13 @@ def get_precision() -> str:
 
 def _ns():
     return _cfg["ns"]
+
+
+def set_fused_timer(sink):
+    """Diagnostic: a list that receives (start_event, end_event, n_params, operand_bytes) for every fused
+    weight-gradient + AdamW launch (bench.py's roofline figure), or None to switch it off.  operand_bytes = the
+    tile-list entries and the bf16 dY^T the launch reads."""
+    _cfg["fused_timer"] = sink
 
 
 def next_seed() -> int:
@@ -224,9 +231,10 @@ def linear(x, W, b=None):
 # ------------------------------------------------------------------------------------------------
 class FcnnLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, cov, W, b, gamma, beta, slope, p_drop, seed, eps, shadow=None):
+    def forward(ctx, x, cov, W, b, gamma, beta, slope, p_drop, seed, eps, shadow=None, fused=None):
         """x: dense [B, F] tensor or BatchTiles; cov: dense [B, C] or None; W: [H, F + C];
-        shadow: bf16 copy of W for the bf16 sparse kernels (or None)."""
+        shadow: bf16 copy of W for the bf16 sparse kernels (or None); fused: FusedFirstLayer handle when the AdamW
+        step of W runs inside the weight-gradient kernel (or None)."""
         L = _lib.lib()
         sparse = isinstance(x, BatchTiles)
         Wc = _f32c(W)
@@ -275,6 +283,7 @@ class FcnnLayerFn(torch.autograd.Function):
         ctx.save_for_backward(xs, covc, Wc, g_, b_, xhat, rstd)
         ctx.cfg = (slope, p_drop, seed, Bn, H, F, C_, ns, b is not None)
         ctx.use_bf = use_bf
+        ctx.fused = fused if (use_bf and C_ == 0 and Ftot % 4 == 0) else None
         return out
 
     @staticmethod
@@ -295,16 +304,33 @@ class FcnnLayerFn(torch.autograd.Function):
                                     _lib.ptr(dbeta), _lib.ptr(dbias), ws.data_ptr(), _lib.stream()), "scp_ln_act_bwd")
         dx = dW = None
         if ctx.needs_input_grad[2]:
-            dW = torch.empty((H, Ftot), dtype=torch.float32, device=dev)
+            if ctx.fused is None:
+                dW = torch.empty((H, Ftot), dtype=torch.float32, device=dev)
             if ctx.sparse and ctx.use_bf:
                 t = ctx.tiles
                 ldt = (Bn + 63) // 64 * 64
                 dYT = torch.empty((H, ldt), dtype=torch.bfloat16, device=dev)
                 _lib.check(L.scp_transpose_bf16(dY.data_ptr(), Bn, H, H, dYT.data_ptr(), ldt, _lib.stream()),
                            "scp_transpose_bf16")
-                _lib.check(L.scp_spmm_dw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
-                                              dYT.data_ptr(), ldt, dW.data_ptr(), Ftot, _lib.stream()),
-                           "scp_spmm_dw_bf16")
+                if ctx.fused is not None:
+                    # weight gradient + AdamW step of W in one kernel: dW never reaches HBM, autograd gets no gradient
+                    m_, v_, sh_, hp = ctx.fused.begin_step(W)
+                    dW = None
+                    tm = _cfg["fused_timer"]
+                    if tm is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                                                        dYT.data_ptr(), ldt, W.data_ptr(), Ftot, m_.data_ptr(),
+                                                        v_.data_ptr(), sh_.data_ptr(), sh_.shape[1], *hp,
+                                                        _lib.stream()), "scp_spmm_dw_adamw_bf16")
+                    if tm is not None:
+                        e1.record()
+                        tm.append((e0, e1, H * Ftot, int(t.nnz) * (8 if t.val is not None else 4) + 2 * H * ldt))
+                else:
+                    _lib.check(L.scp_spmm_dw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                                                  dYT.data_ptr(), ldt, dW.data_ptr(), Ftot, _lib.stream()),
+                               "scp_spmm_dw_bf16")
             elif ctx.sparse:
                 t = ctx.tiles
                 _lib.check(L.scp_spmm_dw(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), dY.data_ptr(), H,
@@ -319,14 +345,17 @@ class FcnnLayerFn(torch.autograd.Function):
         if (not ctx.sparse) and ctx.needs_input_grad[0]:
             dx = torch.empty((Bn, F), dtype=torch.float32, device=dev)
             gemm_nt_auto(Bn, F, H, dY, H, 1, W, 1, Ftot, dx, ns=ns)
-        return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None, None
+        return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
 def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
-    shadow = None
+    shadow = fused = None
     if isinstance(x, BatchTiles) and _ns() == 1 and W.is_cuda and W.dtype == torch.float32 and W.is_contiguous():
         shadow = shadow_of(W)
-    return FcnnLayerFn.apply(x, cov, W, b, gamma, beta, float(slope), float(p_drop), int(seed), float(eps), shadow)
+        if cov is None and torch.is_grad_enabled() and W.requires_grad:
+            fused = fused_handle(W)
+    return FcnnLayerFn.apply(x, cov, W, b, gamma, beta, float(slope), float(p_drop), int(seed), float(eps), shadow,
+                             fused)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -506,14 +535,15 @@ class RawRowsLossFn(torch.autograd.Function):
         Lr = _f32c(L).reshape(-1)
         _lib.require_cuda(z, y, Lr)
         B, G = z.shape
+        fast = 1 if get_precision() == "bf16" else 0
         lse, T = _empty((B,), z), _empty((B,), z)
         part = torch.empty(B, dtype=torch.float64, device=z.device)
         loss = _empty((1,), z)
         _lib.check(lib.scp_raw_rows_fwd(z.data_ptr(), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(), B, G,
-                                        lse.data_ptr(), T.data_ptr(), part.data_ptr(), loss.data_ptr(), _lib.stream()),
+                                        fast, lse.data_ptr(), T.data_ptr(), part.data_ptr(), loss.data_ptr(), _lib.stream()),
                    "scp_raw_rows_fwd")
         ctx.save_for_backward(z, pi, Lr, y, lse, T)
-        ctx.l_shape = L.shape
+        ctx.l_shape, ctx.fast = L.shape, fast
         return loss[0].clone()
 
     @staticmethod
@@ -526,7 +556,7 @@ class RawRowsLossFn(torch.autograd.Function):
         dpi = None if pi is None else torch.empty_like(pi)
         dL = _empty((B,), z) if ctx.needs_input_grad[2] else None
         _lib.check(lib.scp_raw_rows_bwd(z.data_ptr(), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(), lse.data_ptr(),
-                                        T.data_ptr(), g.data_ptr(), B, G, dz.data_ptr(), G, _lib.ptr(dpi), G,
+                                        T.data_ptr(), g.data_ptr(), B, G, ctx.fast, dz.data_ptr(), G, _lib.ptr(dpi), G,
                                         _lib.ptr(dL), _lib.stream()), "scp_raw_rows_bwd")
         return dz, dpi, (None if dL is None else dL.reshape(ctx.l_shape)), None
 
@@ -639,6 +669,56 @@ def relu_softmax_rows(z, fs=None, apply_relu=True, want_theta=False):
 # ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------
+class FusedFirstLayer:
+    """Registration of a first-layer weight whose AdamW step runs inside its weight-gradient kernel
+    (FusedAdamW.fuse_first_layer).  Holds weak references only; the registry below is keyed by id(parameter), so
+    nothing is attached to the Parameter object itself (it stays picklable / deep-copyable as before)."""
+
+    def __init__(self, opt, param, group):
+        self._opt, self._param, self.group = weakref.ref(opt), weakref.ref(param), group
+        self.pending = False
+
+    @property
+    def opt(self):
+        return self._opt()
+
+    @property
+    def param(self):
+        return self._param()
+
+    def begin_step(self, W):
+        """Called by the layer's backward: optimiser state and hyper-parameters of the step about to be applied."""
+        p, opt = self.param, self.opt
+        if p is None or opt is None or W.data_ptr() != p.data_ptr():
+            raise RuntimeError("fused first layer: backward sees a copy of the weights, not the registered parameter")
+        if self.pending:
+            raise RuntimeError("fused first layer: two backward() passes without optimizer.step()")
+        st = opt.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        t = st["step"] + 1
+        b1, b2 = self.group["betas"]
+        sh = shadow_of(p)
+        self.pending = True
+        return st["exp_avg"], st["exp_avg_sq"], sh, (self.group["lr"], self.group["weight_decay"], b1, b2,
+                                                     self.group["eps"], 1 - b1 ** t, 1 - b2 ** t, 1.0)
+
+
+_fused = {}            # id(parameter) -> FusedFirstLayer
+
+
+def fused_handle(W):
+    h = _fused.get(id(W))
+    if h is None:
+        return None
+    if h.param is not W or h.opt is None:
+        del _fused[id(W)]
+        return None
+    return h
+
+
 class FusedAdamW(torch.optim.Optimizer):
     """Drop-in for torch.optim.AdamW as the reference configures it (model.py:698-701): same param_groups
     / state layout ('step', 'exp_avg', 'exp_avg_sq'), one fused multi-tensor HIP launch per step."""
@@ -647,6 +727,32 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    # -- AdamW step of the sparse first-layer weights inside their weight-gradient kernel ----------------------
+    def fuse_first_layer(self, *params):
+        """Opt in for `params` (2-D first-layer weights of a HipFCNN fed with BatchTiles, precision 'bf16', no
+        covariate block): their gradient is consumed by the AdamW update in the epilogue of the kernel that computes
+        it, during backward(), and step() only advances their step counter.  Same arithmetic as step(); meant for
+        single-process training with exactly one backward() per step() (no gradient exchange, clipping or
+        accumulation in between).  Layers that do not meet the conditions keep the ordinary path."""
+        group_of = {id(q): g for g in self.param_groups for q in g["params"]}
+        for p in params:
+            if id(p) not in group_of:
+                raise ValueError("fuse_first_layer: parameter is not managed by this optimiser")
+            if p.ndim != 2:
+                raise ValueError("fuse_first_layer: expects 2-D weights")
+            for k in [k for k, h in _fused.items() if h.param is None or h.opt is None]:
+                del _fused[k]
+            _fused[id(p)] = FusedFirstLayer(self, p, group_of[id(p)])
+
+    def unfuse(self):
+        for g in self.param_groups:
+            for p in g["params"]:
+                h = fused_handle(p)
+                if h is not None and h.opt is self:
+                    if h.pending:
+                        raise RuntimeError("unfuse: a fused update is pending, call step() first")
+                    del _fused[id(p)]
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
@@ -660,6 +766,15 @@ class FusedAdamW(torch.optim.Optimizer):
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
+                fz = _fused.get(id(p))
+                if fz is not None and fz.pending and fz.opt is self and fz.param is p:
+                    if grad_scale != 1.0:
+                        raise RuntimeError("FusedAdamW: grad_scale is not available for weights updated during backward()")
+                    if p.grad is not None:
+                        raise RuntimeError("FusedAdamW: a weight updated during backward() also received a gradient")
+                    self.state[p]["step"] += 1
+                    fz.pending = False
+                    continue
                 if p.grad is None:
                     continue
                 _lib.require_cuda(p)

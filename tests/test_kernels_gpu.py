@@ -343,6 +343,19 @@ def test_zinb_row_loss_vs_oracle(S, B, F, K, sf):
         lg = S.pkg.loss.raw_loss(x=tiles.to_dense(), px_mu_rate=outs[2], px_theta=outs[1], px_mu_scale=outs[0],
                                  px_pi=outs[3], likelihood="zinb")
     close(lg, lo, rtol=5e-5, atol=0, what="zinb loss (generic path)")
+    # precision mode 'bf16' (bf16 GEMM operands, hardware exp / log in the row kernels): loss within 1e-2 relative
+    S.ops.set_precision("bf16")
+    try:
+        for prm in dec.parameters():
+            prm.grad = None
+        hb = h.clone().to(S.dev).requires_grad_(True)
+        lb = dec.fused_loss(hb, None, tiles.lib.reshape(-1, 1) if sf else None, None if sf else ld.detach(), tiles, "zinb")
+        lb.backward()
+        close(lb, lo, rtol=1e-2, atol=0, what="zinb loss (bf16 mode)")
+        gb, gr = dec.output_mean[0].bias.grad, ref[2].grad
+        assert relerr(gb, gr) < 5e-2
+    finally:
+        S.ops.set_precision("fp32")
 
 
 def test_ber_eval_mode_matches_train_loss(S):
@@ -556,3 +569,54 @@ def test_foscttm_fosfttm_gpu(S):
     x = rng.normal(size=(1000, 70)).astype(np.float32); y = (x + 5 * rng.normal(size=x.shape)).astype(np.float32)
     av, _, _ = S.O.foscttm(x, y)
     assert abs(E.FOSCTTM(x, y) - av) < 2e-6       # fp32 summation order can flip a handful of near-ties in 1e6 pairs
+
+
+@pytest.mark.parametrize("B,F,H,binary", [(300, 1000, 72, False), (1024, 4100, 200, True), (64, 256, 128, False)])
+def test_first_layer_wgrad_with_adamw_epilogue(S, B, F, H, binary):
+    """scp_spmm_dw_adamw_bf16 (weight gradient + AdamW step in one kernel) against the two-kernel path
+    (scp_spmm_dw_bf16 then scp_adamw_multi) over three steps: weights, both moments and the bf16 shadow."""
+    ops = S.ops
+    ops.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(F)
+        x = rand_csr(rng, B, F, 0.08, binary=binary)
+        tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(x, S.dev, binary=binary), np.arange(B))
+        g = torch.Generator().manual_seed(F)
+        W0 = torch.randn(H, F, generator=g) * 0.05
+        b0 = torch.randn(H, generator=g) * 0.1
+        res = {}
+        for mode in ("plain", "fused"):
+            W = torch.nn.Parameter(W0.clone().to(S.dev)); b = torch.nn.Parameter(b0.clone().to(S.dev))
+            opt = ops.FusedAdamW([{"params": [W], "weight_decay": 1e-2, "lr": 1e-2}, {"params": [b], "weight_decay": 0.0, "lr": 1e-2}])
+            if mode == "fused":
+                opt.fuse_first_layer(W)
+            gd = torch.Generator(device=S.dev).manual_seed(7)
+            for step in range(3):
+                out = ops.fcnn_layer(tiles, None, W, b, None, None, 0.01)
+                dout = torch.randn(B, H, device=S.dev, generator=gd)
+                opt.zero_grad()
+                out.backward(dout)
+                assert (W.grad is None) == (mode == "fused")
+                opt.step()
+            st = opt.state[W]
+            assert st["step"] == 3
+            res[mode] = [W.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                         ops.shadow_of(W, create=False).clone(), b.detach().clone()]
+        for nm, a, r_ in zip(("W", "exp_avg", "exp_avg_sq", "shadow", "bias"), res["fused"], res["plain"]):
+            a, r_ = a.float(), r_.float()
+            # fp32 state: same arithmetic, up to the compiler's fma contraction in the two kernels; the shadow may
+            # then differ by one bf16 rounding step where a weight sits on a rounding boundary
+            tol = 2.0 ** -7 if nm == "shadow" else 1e-6
+            assert float((a - r_).abs().max()) <= tol * float(r_.abs().max()) + 1e-12, nm
+        # the shadow is exactly the bf16 rounding of the master weights it was written with
+        assert torch.equal(res["fused"][3][:, :F], res["fused"][0].bfloat16())
+        # the weights really moved, and the guard against a second backward without step() works
+        assert float((res["fused"][0] - W0.to(S.dev)).abs().max()) > 1e-3
+        W = torch.nn.Parameter(W0.clone().to(S.dev))
+        opt = ops.FusedAdamW([W], lr=1e-3)
+        opt.fuse_first_layer(W)
+        ops.fcnn_layer(tiles, None, W, None, None, None, 1.0).sum().backward()
+        with pytest.raises(RuntimeError):
+            ops.fcnn_layer(tiles, None, W, None, None, None, 1.0).sum().backward()
+    finally:
+        ops.set_precision("fp32")
