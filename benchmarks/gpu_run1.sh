@@ -1,8 +1,10 @@
 set -e
-export TMPDIR=/tmp
-timeout -k 10 300 python bench.py --cpu-steps 0 > gpurun_out/b_default.log 2>&1 || { tail -20 gpurun_out/b_default.log; exit 1; }
-tail -1 gpurun_out/b_default.log
-timeout -k 10 300 python bench.py --cpu-steps 0 --no-fuse-opt > gpurun_out/b_nofuse.log 2>&1
-tail -1 gpurun_out/b_nofuse.log
-timeout -k 10 400 python -u -m pytest tests/test_trajectory_gpu.py -x -q --timeout 120 --timeout-method thread > gpurun_out/t_traj.log 2>&1 || { tail -30 gpurun_out/t_traj.log; exit 1; }
-tail -1 gpurun_out/t_traj.log
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/pmc_f $R/gpurun_out/pmc_w $R/gpurun_out/kt
+cd $R
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python3 bench.py --steps 3 --warmup 1 --cpu-steps 0 --streams 1 > gpurun_out/pmc_f.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python3 bench.py --steps 3 --warmup 1 --cpu-steps 0 --streams 1 > gpurun_out/pmc_w.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -o kt -- python3 bench.py --steps 10 --warmup 3 --cpu-steps 0 > gpurun_out/kt.log 2>&1
+tail -1 gpurun_out/kt.log
+ls -la gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/kt
