@@ -35,6 +35,10 @@ int scp_tiles_build(const int64_t* indptr, const int32_t* indices, const float* 
  * (ZINB, Gaussian: loss.py:22-27, 46-51); replaces the dense gather of model.py:26-38 */
 int scp_tiles_to_dense(int B, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val, float* out, long ld,
                        void* stream);
+/* Optional input pre-transform on a minibatch tile list, in place (no counterpart in the reference, which feeds raw
+ * counts: model.py:492-510; opt-in, default off): mode 1: v <- log1p(v); mode 2: v <- log1p(v * scale / lib[cell]). */
+int scp_tiles_transform(int B, int F, const int32_t* ptr, const int32_t* key, float* val, const float* lib, int mode,
+                        float scale, void* stream);
 
 /* ---- first encoder layer on sparse counts: nn.Linear(F_in, H) of FCNN (utils.py:57) applied to
  *      the dense x in Input_Module (model.py:128-130, 136-140), forward and weight gradient ---- */

@@ -469,3 +469,18 @@ def fosfttm(query, reference):
     D = pairwise_sq_dists(query, reference)
     f = np.array([np.sum(D[i, i] < D[i, :]) / (n - 1) for i in range(n)])
     return f.sum() / n, f
+
+
+def input_transform(x, mode, scale=1e4):
+    """Opt-in encoder-input pre-transform of the build (no counterpart upstream, where model.py:492-510 feeds raw
+    counts; parity unpinned, this is the defining formula): 'log1p' -> log1p(x); 'log1p_norm' ->
+    log1p(x * scale / rowsum(x)), rows without counts left at zero."""
+    x = torch.as_tensor(x, dtype=torch.float32)
+    if mode is None:
+        return x
+    if mode == "log1p":
+        return torch.log1p(x)
+    if mode == "log1p_norm":
+        lib = torch.nan_to_num(x, nan=0.0).sum(1, keepdim=True)
+        return torch.log1p(torch.where(lib > 0, x * (scale / lib.clamp_min(1e-30)), x))
+    raise ValueError(mode)

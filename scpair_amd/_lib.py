@@ -35,6 +35,7 @@ _SIGS = {
     "scp_tiles_ptr_len": (L, [I, I]),
     "scp_tiles_ws_len": (L, [I, I]),
     "scp_tiles_to_dense": (I, [I, I, P, P, P, P, L, P]),
+    "scp_tiles_transform": (I, [I, I, P, P, P, P, I, F, P]),
     "scp_tiles_build": (I, [P, P, P, P, I, I, P, P, P, P, P, P, P]),
     "scp_gemm_split_count": (I, [I, I]),
     "scp_spmm_fwd": (I, [I, I, I, P, P, P, P, L, P, L, P, I, I, P]),

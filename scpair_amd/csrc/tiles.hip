@@ -299,3 +299,34 @@ extern "C" int scp_tiles_to_dense(int B, int F, const int32_t* ptr, const int32_
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
+
+// ---- optional input pre-transform, applied to the minibatch tile list in place (opt-in; the reference feeds raw
+//      counts, so the default is off): mode 1: v <- log1p(v); mode 2: v <- log1p(v * scale / lib[cell]) with lib the
+//      cell's library size.  Only the batch's own entries are touched; no normalised matrix is ever materialised. ----
+__global__ __launch_bounds__(256) void tiles_transform_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ key,
+                                                              float* __restrict__ val, int B, int F,
+                                                              const float* __restrict__ lib, int mode, float scale) {
+  int cb = blockIdx.y;
+  int e0 = ptr[(long)cb * F], e1 = ptr[(long)(cb + 1) * F];
+  for (int e = e0 + blockIdx.x * 256 + threadIdx.x; e < e1; e += gridDim.x * 256) {
+    float v = val[e];
+    if (mode == 2) {
+      int c = cb * 64 + (key[e] & 63);
+      float l = (c < B) ? lib[c] : 1.f;
+      v = (l > 0.f) ? v * (scale / l) : v;
+    }
+    val[e] = log1pf(v);
+  }
+}
+
+extern "C" int scp_tiles_transform(int B, int F, const int32_t* ptr, const int32_t* key, float* val, const float* lib,
+                                   int mode, float scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SCP_CHECK(B > 0 && F > 0 && ptr && key && val, SCP_ERR_ARG, "scp_tiles_transform: bad argument (values are required)");
+  SCP_CHECK(mode == 1 || (mode == 2 && lib && scale > 0.f), SCP_ERR_ARG,
+            "scp_tiles_transform: mode must be 1 (log1p) or 2 (log1p of library-size normalised counts, needs lib and scale > 0)");
+  int ncb = (B + 63) / 64;
+  hipLaunchKernelGGL(tiles_transform_kernel, dim3(64, ncb), dim3(256), 0, stream, ptr, key, val, B, F, lib, mode, scale);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}

@@ -347,7 +347,7 @@ class scPair_object():
                  memory_efficient_loading=True,
                  val_chunk=4096,
                  verbose=True,
-                 grad_sync=None, fuse_optimizer=True):
+                 grad_sync=None, fuse_optimizer=True, input_transform=None):
         self.scobj = scobj
         self.modalities = modalities
         self.modality_names = list(modalities.keys())
@@ -398,6 +398,14 @@ class scPair_object():
         self.verbose = verbose
         self.grad_sync = grad_sync          # data-parallel hook (scpair_amd.distributed.GradSync) or None
         self.fuse_optimizer = fuse_optimizer  # AdamW step of the first-layer weights inside their dW kernel (1 process)
+        # Opt-in input pre-transform per modality, e.g. {'Gene Expression': 'log1p_norm'} or {'Gene Expression':
+        # ('log1p_norm', 1e4)}: applied to encoder inputs only, on the fly in the minibatch tile list.  The reference
+        # has no normalisation anywhere (model.py:492-510 feeds raw counts), so the default None keeps parity.
+        self.input_transform = dict(input_transform or {})
+        for k_, v_ in self.input_transform.items():
+            mode_ = v_[0] if isinstance(v_, (tuple, list)) else v_
+            if mode_ not in (None, "log1p", "log1p_norm"):
+                raise ValueError(f"input_transform[{k_!r}] must be None, 'log1p' or 'log1p_norm'")
         self.scaler = None
         self.history = {}
         if self.add_linear_layer is True and self.mapping_non_neg is True:
@@ -491,12 +499,20 @@ class scPair_object():
                 setattr(self, f"{split}_metadata", _Index(n))
         self._csr_cache = {}
 
-    def _csr(self, d, key):
+    def _csr(self, d, key, as_input=False):
+        """Device CSR of d[key] (cached).  as_input=True: the encoder-input view, which carries the modality's
+        opt-in pre-transform; label roles always get the raw counts."""
         cache = self.__dict__.setdefault("_csr_cache", {})
         ck = (id(d), key)
         if ck not in cache:
             cache[ck] = _to_csr(d[key], self.device)
-        return cache[ck]
+        csr = cache[ck]
+        if as_input and self.input_transform:
+            tf = next((v for m, v in self.input_transform.items() if key.startswith(m + '_')), None)
+            if tf is not None:
+                mode, scale = (tf[0], tf[1]) if isinstance(tf, (tuple, list)) else (tf, 1e4)
+                csr = csr.with_transform(mode, scale)
+        return csr
 
     def run(self):
         self.encoder_dict, self.decoder_dict = self.train_predicting_networks(*self.data_loader_builder())
@@ -574,7 +590,7 @@ class scPair_object():
                 if hasattr(self, f'data_loader_dict_{split}'):
                     d = getattr(self, f'data_loader_dict_{split}')
                     cov = self._cov_dev(d, f'{modality}_{split}_cov')
-                    emb = self._encode(encoder_cal, self._csr(d, f'{modality}_{split}_mtx'), cov)
+                    emb = self._encode(encoder_cal, self._csr(d, f'{modality}_{split}_mtx', as_input=True), cov)
                     embeddings[f'{modality}_{split}'] = emb.cpu().detach()
                     df_embeddings[f'{modality}_{split}'] = pd.DataFrame(
                         embeddings[f'{modality}_{split}'].numpy(), index=getattr(self, f'{split}_metadata').index)
@@ -626,7 +642,7 @@ class scPair_object():
                 lat = None
                 if need_lat:
                     icov = self._cov_dev(d, f'{input_modality}_{split}_cov')
-                    _, lat = self._encode(encoder_cal, self._csr(d, f'{input_modality}_{split}_mtx'), icov, want_lib=True)
+                    _, lat = self._encode(encoder_cal, self._csr(d, f'{input_modality}_{split}_mtx', as_input=True), icov, want_lib=True)
                 lib = torch.ones(1, device=self.device) if dist in ['ber', 'nb', 'zinb'] else None
                 outs = []
                 for r0 in range(0, emb.shape[0], self.val_chunk):
@@ -710,9 +726,9 @@ class scPair_object():
             output_modality = self._other(input_modality)
             prediction_order = {'input': input_modality, 'output': output_modality}
             self._say('Set up predicting networks:', prediction_order)
-            xtr = self._csr(train_data_dict, input_modality + '_train_mtx')
+            xtr = self._csr(train_data_dict, input_modality + '_train_mtx', as_input=True)
             ytr = self._csr(train_data_dict, output_modality + '_train_mtx')
-            xva = self._csr(val_data_dict, input_modality + '_val_mtx')
+            xva = self._csr(val_data_dict, input_modality + '_val_mtx', as_input=True)
             yva = self._csr(val_data_dict, output_modality + '_val_mtx')
             ctr = self._cov_dev(train_data_dict, input_modality + '_train_cov')
             cva = self._cov_dev(val_data_dict, input_modality + '_val_cov')
@@ -880,9 +896,13 @@ class scPair_object():
         other = [mn for mn in self.modalities.keys() if mn != name][0]
         X = unimodal_scobj.X if hasattr(unimodal_scobj, "X") else unimodal_scobj
         uni = _to_csr(X, self.device)
-        btr = self._csr(self.data_loader_dict_train, name + '_train_mtx')
-        bva = self._csr(self.data_loader_dict_val, name + '_val_mtx')
-        bte = self._csr(self.data_loader_dict_test, name + '_test_mtx') if hasattr(self, 'data_loader_dict_test') else None
+        tf = self.input_transform.get(name)
+        if tf is not None:
+            uni = uni.with_transform(*((tf[0], tf[1]) if isinstance(tf, (tuple, list)) else (tf, 1e4)))
+        btr = self._csr(self.data_loader_dict_train, name + '_train_mtx', as_input=True)
+        bva = self._csr(self.data_loader_dict_val, name + '_val_mtx', as_input=True)
+        bte = self._csr(self.data_loader_dict_test, name + '_test_mtx', as_input=True) \
+            if hasattr(self, 'data_loader_dict_test') else None
         enc = copy.deepcopy(self.encoder_dict[name + ' to ' + other]).to(self.device)
         enc.eval()
         uni_label = self._encode(enc, uni, None)

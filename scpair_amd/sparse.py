@@ -73,6 +73,28 @@ class DeviceCSR:
         m = sp.csr_matrix((a[rows, cols].astype(np.float32), (rows, cols)), shape=a.shape)
         return cls(m.indptr, m.indices, m.data, m.shape, device)
 
+    # Optional input pre-transform (opt-in; the reference feeds raw counts): None, ("log1p", 1.0) or
+    # ("log1p_norm", scale).  It is applied to every minibatch tile list built from this object, on the batch's own
+    # entries; the resident CSR keeps the raw counts, and `.lib` of a tile list stays the raw library size.
+    transform = None
+
+    def with_transform(self, mode, scale=1e4):
+        """A view of the same device arrays whose minibatches are pre-transformed: mode 'log1p' -> log1p(x),
+        'log1p_norm' -> log1p(x * scale / library_size(cell)).  Use it for the INPUT role only; labels of the
+        count likelihoods must stay raw counts."""
+        if mode is None:
+            return self
+        if mode not in ("log1p", "log1p_norm"):
+            raise ValueError("input transform must be None, 'log1p' or 'log1p_norm'")
+        if self.values is None:
+            raise ValueError("input transforms need explicit values (binary matrices with implicit ones have none)")
+        if mode == "log1p_norm" and not scale > 0:
+            raise ValueError("log1p_norm needs scale > 0")
+        import copy
+        v = copy.copy(self)
+        v.transform = (mode, float(scale) if mode == "log1p_norm" else 1.0)
+        return v
+
     @property
     def n_rows(self):
         return self.shape[0]
@@ -129,13 +151,19 @@ class BatchTiles:
         self.ptr = torch.empty(L.scp_tiles_ptr_len(self.B, self.F), dtype=torch.int32, device=dev)
         self.key = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)
         self.val = None if csr.values is None else torch.empty(max(self.nnz, 1), dtype=torch.float32, device=dev)
-        self.lib = torch.empty(self.B, dtype=torch.float32, device=dev) if want_lib else None
+        tf = csr.transform
+        need_lib = want_lib or (tf is not None and tf[0] == "log1p_norm")
+        self.lib = torch.empty(self.B, dtype=torch.float32, device=dev) if need_lib else None
         self.nnan = torch.empty(1, dtype=torch.int32, device=dev)   # cleared by scp_tiles_build
         ws = torch.empty(L.scp_tiles_ws_len(self.B, self.F), dtype=torch.int32, device=dev)
         _lib.check(L.scp_tiles_build(_lib.ptr(csr.indptr), _lib.ptr(csr.indices), _lib.ptr(csr.values),
                                      _lib.ptr(rows_dev), self.B, self.F, _lib.ptr(self.ptr), _lib.ptr(self.key),
                                      _lib.ptr(self.val), _lib.ptr(self.lib), _lib.ptr(self.nnan), _lib.ptr(ws),
                                      _lib.stream()), "scp_tiles_build")
+        if tf is not None:
+            _lib.check(L.scp_tiles_transform(self.B, self.F, _lib.ptr(self.ptr), _lib.ptr(self.key), _lib.ptr(self.val),
+                                             _lib.ptr(self.lib), 2 if tf[0] == "log1p_norm" else 1, tf[1],
+                                             _lib.stream()), "scp_tiles_transform")
         self.csr = csr
 
     @property

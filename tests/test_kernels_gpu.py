@@ -620,3 +620,33 @@ def test_first_layer_wgrad_with_adamw_epilogue(S, B, F, H, binary):
             ops.fcnn_layer(tiles, None, W, None, None, None, 1.0).sum().backward()
     finally:
         ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("mode,scale", [("log1p", 1.0), ("log1p_norm", 1e4), ("log1p_norm", 37.5)])
+def test_input_transform_on_tile_list(S, mode, scale):
+    """Opt-in log1p / library-size normalisation of encoder inputs, applied to the minibatch tile list: against the
+    oracle's formula on the dense rows; the resident CSR, the library sizes and the default (no transform) are
+    unchanged; binary matrices with implicit ones are refused."""
+    O = S.O
+    rng = np.random.default_rng(5)
+    B, F = 200, 777
+    x = rand_csr(rng, 260, F, 0.07)
+    x = x.tolil(); x[3, :] = 0; x = x.tocsr(); x.eliminate_zeros()          # an empty cell
+    csr = S.sparse.DeviceCSR.from_scipy(x, S.dev)
+    rows = rng.permutation(260)[:B]
+    dense = torch.tensor(np.asarray(x.todense(), dtype=np.float32))[rows]
+    raw = S.sparse.BatchTiles(csr, rows, want_lib=True)
+    t = S.sparse.BatchTiles(csr.with_transform(mode, scale), rows, want_lib=True)
+    close(t.to_dense(), O.input_transform(dense, mode, scale), rtol=2e-6, atol=1e-7, what=mode)
+    assert torch.equal(t.lib.cpu(), dense.sum(1)) and torch.equal(raw.to_dense().cpu(), dense)
+    nptr = ((B + 63) // 64) * F + 1
+    assert torch.equal(t.ptr[:nptr], raw.ptr[:nptr])       # same buckets (entries inside a bucket carry no order)
+    # feeds the first layer like any other tile list
+    S.ops.set_precision("fp32")
+    W = torch.randn(16, F) * 0.1
+    out = S.ops.fcnn_layer(t, None, W.to(S.dev), None, None, None, 1.0)
+    close(out, O.input_transform(dense, mode, scale) @ W.t(), rtol=1e-4, atol=1e-4, what="first layer on transformed input")
+    with pytest.raises(ValueError):
+        S.sparse.DeviceCSR.from_scipy(x, S.dev, binary=True).with_transform(mode, scale)
+    with pytest.raises(ValueError):
+        csr.with_transform("sqrt")
