@@ -19,6 +19,8 @@ dec = S.VAE_DECODER(input_dim=G, input_batch_num=0, hidden_dim=[900], latent_dim
                     sample_factor=True, feature_factor=False, distribution=lik,
                     dispersion="feature-cell").to(dev)
 opt = S.FusedAdamW(list(enc.parameters()) + list(dec.parameters()), lr=1e-3, weight_decay=0.0)
+if os.environ.get("FUSE", "1") == "1":
+    opt.fuse_first_layer(enc.enc_hidden[0].weight)      # AdamW step of the 900 x 20 k encoder weights in their dW kernel
 enc.train(); dec.train()
 rng = np.random.default_rng(0)
 def step():

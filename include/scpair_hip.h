@@ -158,16 +158,20 @@ int scp_ber_prob(const float* z, long ldz, int rows, int cols, const float* lrow
 int scp_relu_softmax_rows(const float* z, long ldz, int rows, int cols, const float* fs, int apply_relu,
                           float* scale, long lds, float* theta /* nullable */, long ldt, void* stream);
 
-/* ---- (ZI)NB decoder heads on materialised pre-activations (ZINB predictor with its G x G zero-inflation layer,
- *      model.py:228-259; loss.py:46-51; scVI_distribution.py:29-105), dispersion 'feature-cell', no feature factor:
- *      z [B][G] = output_mean Linear output, pi [B][G] zero-inflation logits or null (plain NB), y dense labels,
- *      L [B] library term.  fast != 0: hardware exp / log / reciprocal (precision mode 'bf16').
- *      fwd: loss, lse [B], T [B] (kept for bwd), part: B doubles.  bwd: dz, dpi, dL (nullable) ---- */
-int scp_raw_rows_fwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy, const float* L,
-                     int B, int G, int fast, float* lse, float* T, double* part, float* loss, void* stream);
-int scp_raw_rows_bwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy, const float* L,
-                     const float* lse, const float* T, const float* gout, int B, int G, int fast, float* dz, long lddz,
-                     float* dpi, long lddp, float* dL, void* stream);
+/* ---- (ZI)NB decoder heads on materialised pre-activations (loss.py:46-51; scVI_distribution.py:29-105), no feature
+ *      factor.  z [B][G] = output of the mean Linear, pi [B][G] zero-inflation logits or null (plain NB), y dense
+ *      labels, L [B] library term (observed library size, exp(LeakyReLU(latent_lib)), or ones).
+ *        tz == null: the ZINB predictor with its G x G zero-inflation layer (model.py:228-259, dispersion
+ *                    'feature-cell'): a = relu(z), scale = softmax(a), theta = exp(a);
+ *        tz [B][G] : the VAE decoder heads (pairedVAE.py:147-187): scale = softmax(z), theta = softplus(tz) + 1e-8.
+ *      fast != 0: hardware exp / log / reciprocal (precision mode 'bf16').
+ *      fwd: loss, lse [B], T [B] (kept for bwd), part: B doubles.  bwd: dz, dtz (with tz), dpi (with pi), dL (nullable) ---- */
+int scp_raw_rows_fwd(const float* z, long ldz, const float* tz, long ldt, const float* pi, long ldp, const float* y,
+                     long ldy, const float* L, int B, int G, int fast, float* lse, float* T, double* part, float* loss,
+                     void* stream);
+int scp_raw_rows_bwd(const float* z, long ldz, const float* tz, long ldt, const float* pi, long ldp, const float* y,
+                     long ldy, const float* L, const float* lse, const float* T, const float* gout, int B, int G, int fast,
+                     float* dz, long lddz, float* dtz, long lddt, float* dpi, long lddp, float* dL, void* stream);
 
 /* ---- evaluation metrics (evaluator.py:14-71): neighbour counts behind FOSCTTM / FOSFTTM for paired embeddings
  *      x, y [n][d]: lt12[i] = #{j: D[i][j] < D[i][i]}, lt21[i] = #{j: D[j][i] < D[i][i]},

@@ -71,8 +71,8 @@ _SIGS = {
     "scp_reparam_kl_bwd": (I, [P, P, P, P, P, P, P, L, P, P, P]),
     "scp_ber_prob": (I, [P, L, I, I, P, I, P, P, L, P]),
     "scp_relu_softmax_rows": (I, [P, L, I, I, P, I, P, L, P, L, P]),
-    "scp_raw_rows_fwd": (I, [P, L, P, L, P, L, P, I, I, I, P, P, P, P, P]),
-    "scp_raw_rows_bwd": (I, [P, L, P, L, P, L, P, P, P, P, I, I, I, P, L, P, L, P, P]),
+    "scp_raw_rows_fwd": (I, [P, L, P, L, P, L, P, L, P, I, I, I, P, P, P, P, P]),
+    "scp_raw_rows_bwd": (I, [P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, P, L, P, L, P, L, P, P]),
     "scp_fos_counts": (I, [P, L, P, L, I, I, P, P, P, P, P]),
     "scp_adamw_multi": (I, [C.POINTER(AdamTensor), I, F, F, F, P]),
 }

@@ -2,7 +2,9 @@
 // zero-inflation layer needs px_mu as a GEMM operand (model.py:228-259), and the VAE decoder heads.
 //
 //   z  [B][G]  pre-activation of output_mean's Linear          pi [B][G] zero-inflation logits (null: plain NB)
-//   a = relu(z), scale = softmax_row(a), mu = L[b] * scale, theta = exp(a)   (dispersion 'feature-cell')
+//   predictor (tz null): a = relu(z), scale = softmax_row(a), mu = L[b] * scale, theta = exp(a)  ('feature-cell')
+//   VAE decoder (tz [B][G] = output of its dispersion Linear, pairedVAE.py:147-187): a = z (no relu),
+//                        scale = softmax_row(a), mu = L[b] * scale, theta = softplus(tz) + 1e-8
 //   loss = -mean_{b,j} log (ZI)NB(y; mu, theta, pi)            scVI_distribution.py:29-105, loss.py:46-51
 //
 // One workgroup per cell row.  Forward: row log-sum-exp, log-likelihood sum and T = sum_j mu_j dll/dmu_j (the
@@ -23,14 +25,14 @@ struct RawTerms {
 
 // element terms shared by forward and backward (same arithmetic as nbll_fwd/bwd_kernel in elementwise.hip)
 // FAST (precision mode 'bf16'): hardware exp / log / reciprocal, as in the fused decoders
-template <bool WANT_LL, bool WANT_GRAD, bool FAST>
-__device__ __forceinline__ RawTerms raw_terms(float zv, float xv, float L, float lse, bool zi, float pv) {
+template <bool WANT_LL, bool WANT_GRAD, bool FAST, bool VAE>
+__device__ __forceinline__ RawTerms raw_terms(float zv, float tzv, float xv, float L, float lse, bool zi, float pv) {
   const float eps = 1e-8f;
   RawTerms t;
-  float a = fmaxf(zv, 0.f);
+  float a = VAE ? zv : fmaxf(zv, 0.f);
   float scale = exp_<FAST>(a - lse);
   t.mu = L * scale;
-  t.th = exp_<FAST>(a);
+  t.th = VAE ? softplus_<FAST>(tzv) + 1e-8f : exp_<FAST>(a);
   float m = t.mu, th = t.th;
   float s = th + m + eps;
   float lt = log_<FAST>(th + eps), ls = log_<FAST>(s);
@@ -76,8 +78,9 @@ __device__ __forceinline__ RawTerms raw_terms(float zv, float xv, float L, float
   return t;
 }
 
-template <bool FAST>
+template <bool FAST, bool VAE>
 __global__ __launch_bounds__(256) void raw_rows_fwd_kernel(const float* __restrict__ z, long ldz,
+                                                           const float* __restrict__ tz, long ldt,
                                                            const float* __restrict__ pi, long ldp,
                                                            const float* __restrict__ y, long ldy,
                                                            const float* __restrict__ Lrow, int B, int G,
@@ -89,14 +92,14 @@ __global__ __launch_bounds__(256) void raw_rows_fwd_kernel(const float* __restri
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* zr = z + (long)b * ldz;
   // pass 1: log-sum-exp of relu(z) (max first, then the sum)
-  float m = 0.f;                                   // relu(z) >= 0
+  float m = VAE ? -3.0e38f : 0.f;                  // predictor: relu(z) >= 0
   for (int j = tid; j < G; j += 256) m = fmaxf(m, zr[j]);
   m = wave_max(m);
   if ((tid & 63) == 0) red[tid >> 6] = m;
   __syncthreads();
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float se = 0.f;
-  for (int j = tid; j < G; j += 256) se += exp_<FAST>(fmaxf(zr[j], 0.f) - m);
+  for (int j = tid; j < G; j += 256) se += exp_<FAST>((VAE ? zr[j] : fmaxf(zr[j], 0.f)) - m);
   se = block_sum(se, red);
   if (tid == 0) bc[0] = m + logf(se);
   __syncthreads();
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(256) void raw_rows_fwd_kernel(const float* __restri
   float T = 0.f;
   for (int j = tid; j < G; j += 256) {
     float pv = zi ? pi[(long)b * ldp + j] : 0.f;
-    RawTerms t = raw_terms<true, true, FAST>(zr[j], y[(long)b * ldy + j], L, lse, zi, pv);
+    float tzv = VAE ? tz[(long)b * ldt + j] : 0.f;
+    RawTerms t = raw_terms<true, true, FAST, VAE>(zr[j], tzv, y[(long)b * ldy + j], L, lse, zi, pv);
     ll += (double)t.ll;
     T += t.mu * t.dm;
   }
@@ -128,16 +132,18 @@ __global__ void raw_rows_finish_kernel(const double* __restrict__ part, int B, d
   if (threadIdx.x == 0) loss[0] = (float)(-s / n_total);
 }
 
-template <bool FAST>
+template <bool FAST, bool VAE>
 __global__ __launch_bounds__(256) void raw_rows_bwd_kernel(const float* __restrict__ z, long ldz,
+                                                           const float* __restrict__ tz, long ldt,
                                                            const float* __restrict__ pi, long ldp,
                                                            const float* __restrict__ y, long ldy,
                                                            const float* __restrict__ Lrow,
                                                            const float* __restrict__ lse_in,
                                                            const float* __restrict__ T_in,
                                                            const float* __restrict__ gout, int B, int G,
-                                                           float* __restrict__ dz, long lddz, float* __restrict__ dpi,
-                                                           long lddp, float* __restrict__ dL) {
+                                                           float* __restrict__ dz, long lddz, float* __restrict__ dtz,
+                                                           long lddt, float* __restrict__ dpi, long lddp,
+                                                           float* __restrict__ dL) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const float c = -(gout ? gout[0] : 1.f) / ((float)B * (float)G);
   const float lse = lse_in[b], L = Lrow[b], T = T_in[b];
@@ -145,43 +151,54 @@ __global__ __launch_bounds__(256) void raw_rows_bwd_kernel(const float* __restri
   for (int j = tid; j < G; j += 256) {
     float zv = z[(long)b * ldz + j];
     float pv = zi ? pi[(long)b * ldp + j] : 0.f;
-    RawTerms t = raw_terms<false, true, FAST>(zv, y[(long)b * ldy + j], L, lse, zi, pv);
+    float tzv = VAE ? tz[(long)b * ldt + j] : 0.f;
+    RawTerms t = raw_terms<false, true, FAST, VAE>(zv, tzv, y[(long)b * ldy + j], L, lse, zi, pv);
     float scale = t.mu / L;
-    // softmax backward (g_j = L dm_j): mu dm - scale T ; theta = exp(a) path: dth * th
-    float da = c * (t.mu * t.dm - scale * T + t.dth * t.th);
-    dz[(long)b * lddz + j] = zv > 0.f ? da : 0.f;
+    if (VAE) {
+      // softmax backward (g_j = L dm_j): mu dm - scale T ; theta = softplus(tz) + 1e-8: dth * sigmoid(tz)
+      dz[(long)b * lddz + j] = c * (t.mu * t.dm - scale * T);
+      dtz[(long)b * lddt + j] = c * t.dth * (tzv > 20.f ? 1.f : sigm_<FAST>(tzv));
+    } else {
+      // theta = exp(a) joins the mean path; relu mask
+      float da = c * (t.mu * t.dm - scale * T + t.dth * t.th);
+      dz[(long)b * lddz + j] = zv > 0.f ? da : 0.f;
+    }
     if (zi) dpi[(long)b * lddp + j] = c * t.dp;
   }
   if (dL && tid == 0) dL[b] = c * T / L;
 }
 
-extern "C" int scp_raw_rows_fwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy,
-                                const float* Lrow, int B, int G, int fast, float* lse, float* T, double* part,
-                                float* loss, void* stream_) {
+extern "C" int scp_raw_rows_fwd(const float* z, long ldz, const float* tz, long ldt, const float* pi, long ldp,
+                                const float* y, long ldy, const float* Lrow, int B, int G, int fast, float* lse, float* T,
+                                double* part, float* loss, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(B > 0 && G > 0 && z && y && Lrow && lse && T && part && loss, SCP_ERR_ARG, "scp_raw_rows_fwd: bad argument");
-  if (fast)
-    hipLaunchKernelGGL(raw_rows_fwd_kernel<true>, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, B, G, lse, T, part);
-  else
-    hipLaunchKernelGGL(raw_rows_fwd_kernel<false>, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, B, G, lse, T, part);
+#define RR_FWD(FA, VA)                                                                                             \
+  hipLaunchKernelGGL((raw_rows_fwd_kernel<FA, VA>), dim3(B), dim3(256), 0, stream, z, ldz, tz, ldt, pi, ldp, y, ldy, \
+                     Lrow, B, G, lse, T, part)
+  if (tz) { if (fast) RR_FWD(true, true); else RR_FWD(false, true); }
+  else { if (fast) RR_FWD(true, false); else RR_FWD(false, false); }
+#undef RR_FWD
   SCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(raw_rows_finish_kernel, dim3(1), dim3(256), 0, stream, part, B, (double)B * (double)G, loss);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
 
-extern "C" int scp_raw_rows_bwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy,
-                                const float* Lrow, const float* lse, const float* T, const float* gout, int B, int G,
-                                int fast, float* dz, long lddz, float* dpi, long lddp, float* dL, void* stream_) {
+extern "C" int scp_raw_rows_bwd(const float* z, long ldz, const float* tz, long ldt, const float* pi, long ldp,
+                                const float* y, long ldy, const float* Lrow, const float* lse, const float* T,
+                                const float* gout, int B, int G, int fast, float* dz, long lddz, float* dtz, long lddt,
+                                float* dpi, long lddp, float* dL, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(B > 0 && G > 0 && z && y && Lrow && lse && T && dz, SCP_ERR_ARG, "scp_raw_rows_bwd: bad argument");
   SCP_CHECK((pi == nullptr) == (dpi == nullptr), SCP_ERR_ARG, "scp_raw_rows_bwd: pi and dpi go together");
-  if (fast)
-    hipLaunchKernelGGL(raw_rows_bwd_kernel<true>, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, lse, T, gout,
-                       B, G, dz, lddz, dpi, lddp, dL);
-  else
-    hipLaunchKernelGGL(raw_rows_bwd_kernel<false>, dim3(B), dim3(256), 0, stream, z, ldz, pi, ldp, y, ldy, Lrow, lse, T, gout,
-                       B, G, dz, lddz, dpi, lddp, dL);
+  SCP_CHECK((tz == nullptr) == (dtz == nullptr), SCP_ERR_ARG, "scp_raw_rows_bwd: tz and dtz go together");
+#define RR_BWD(FA, VA)                                                                                             \
+  hipLaunchKernelGGL((raw_rows_bwd_kernel<FA, VA>), dim3(B), dim3(256), 0, stream, z, ldz, tz, ldt, pi, ldp, y, ldy, \
+                     Lrow, lse, T, gout, B, G, dz, lddz, dtz, lddt, dpi, lddp, dL)
+  if (tz) { if (fast) RR_BWD(true, true); else RR_BWD(false, true); }
+  else { if (fast) RR_BWD(true, false); else RR_BWD(false, false); }
+#undef RR_BWD
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

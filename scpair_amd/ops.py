@@ -523,46 +523,53 @@ def nb_decoder_loss(h, W, b, fs, theta_param, lib_L, lat, tiles):
 # (ZI)NB loss on materialised pre-activations (ZINB predictor, VAE heads)
 # ------------------------------------------------------------------------------------------------
 class RawRowsLossFn(torch.autograd.Function):
-    """loss = raw_loss(y, L*softmax(relu(z)), exp(relu(z)), ., pi) (model.py:229-259 with dispersion 'feature-cell'
-    and no feature factor; loss.py:46-51) from the pre-activation z of output_mean's Linear, in one row kernel
-    forward and one backward.  pi = None: plain NB."""
+    """(ZI)NB loss of a decoder head from its materialised pre-activations, one row kernel forward and one backward
+    (loss.py:46-51).  tz None: the predictor's head, raw_loss(y, L*softmax(relu(z)), exp(relu(z)), ., pi)
+    (model.py:229-259, dispersion 'feature-cell', no feature factor).  tz given: the VAE decoder's heads,
+    raw_loss(y, L*softmax(z), softplus(tz) + 1e-8, ., pi) (pairedVAE.py:147-187).  pi None: plain NB."""
 
     @staticmethod
-    def forward(ctx, z, pi, L, y):
+    def forward(ctx, z, pi, L, y, tz):
         lib = _lib.lib()
         z, y = _f32c(z), _f32c(y)
         pi = None if pi is None else _f32c(pi)
+        tz = None if tz is None else _f32c(tz)
         Lr = _f32c(L).reshape(-1)
-        _lib.require_cuda(z, y, Lr)
+        _lib.require_cuda(z, y, Lr, pi, tz)
         B, G = z.shape
+        if y.shape != z.shape or Lr.numel() != B or (pi is not None and pi.shape != z.shape) or \
+                (tz is not None and tz.shape != z.shape):
+            raise ValueError("raw_rows_loss: shape mismatch")
         fast = 1 if get_precision() == "bf16" else 0
         lse, T = _empty((B,), z), _empty((B,), z)
         part = torch.empty(B, dtype=torch.float64, device=z.device)
         loss = _empty((1,), z)
-        _lib.check(lib.scp_raw_rows_fwd(z.data_ptr(), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(), B, G,
-                                        fast, lse.data_ptr(), T.data_ptr(), part.data_ptr(), loss.data_ptr(), _lib.stream()),
-                   "scp_raw_rows_fwd")
-        ctx.save_for_backward(z, pi, Lr, y, lse, T)
+        _lib.check(lib.scp_raw_rows_fwd(z.data_ptr(), G, _lib.ptr(tz), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(),
+                                        B, G, fast, lse.data_ptr(), T.data_ptr(), part.data_ptr(), loss.data_ptr(),
+                                        _lib.stream()), "scp_raw_rows_fwd")
+        ctx.save_for_backward(z, pi, Lr, y, lse, T, tz)
         ctx.l_shape, ctx.fast = L.shape, fast
         return loss[0].clone()
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.lib()
-        z, pi, Lr, y, lse, T = ctx.saved_tensors
+        z, pi, Lr, y, lse, T, tz = ctx.saved_tensors
         B, G = z.shape
         g = _f32c(g).reshape(1)
         dz = torch.empty_like(z)
         dpi = None if pi is None else torch.empty_like(pi)
+        dtz = None if tz is None else torch.empty_like(tz)
         dL = _empty((B,), z) if ctx.needs_input_grad[2] else None
-        _lib.check(lib.scp_raw_rows_bwd(z.data_ptr(), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(), lse.data_ptr(),
-                                        T.data_ptr(), g.data_ptr(), B, G, ctx.fast, dz.data_ptr(), G, _lib.ptr(dpi), G,
-                                        _lib.ptr(dL), _lib.stream()), "scp_raw_rows_bwd")
-        return dz, dpi, (None if dL is None else dL.reshape(ctx.l_shape)), None
+        _lib.check(lib.scp_raw_rows_bwd(z.data_ptr(), G, _lib.ptr(tz), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(),
+                                        lse.data_ptr(), T.data_ptr(), g.data_ptr(), B, G, ctx.fast, dz.data_ptr(), G,
+                                        _lib.ptr(dtz), G, _lib.ptr(dpi), G, _lib.ptr(dL), _lib.stream()),
+                   "scp_raw_rows_bwd")
+        return dz, dpi, (None if dL is None else dL.reshape(ctx.l_shape)), None, dtz
 
 
-def raw_rows_loss(z, pi, L, y):
-    return RawRowsLossFn.apply(z, pi, L, y)
+def raw_rows_loss(z, pi, L, y, tz=None):
+    return RawRowsLossFn.apply(z, pi, L, y, tz)
 
 
 # ------------------------------------------------------------------------------------------------

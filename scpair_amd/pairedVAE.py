@@ -78,6 +78,32 @@ class VAE_DECODER(nn.Module):
     def reconstruction(self, dec_h):
         return self.output(dec_h)
 
+    def fused_loss(self, z, x_batch, lib, latent_lib, labels, likelihood):
+        """raw_loss(labels, *forward(...)) (utils.py:187-190) for the count likelihoods with dispersion
+        'feature-cell' and no feature factor: the three head GEMMs, then softmax / softplus / (ZI)NB likelihood and
+        their backward in the fused row kernels.  None for the other combinations (generic path)."""
+        if likelihood not in ("nb", "zinb") or self.distribution not in ("nb", "zinb") or \
+                self.dispersion != "feature-cell" or self.feature_factor == True:  # noqa: E712
+            return None
+        if likelihood == "zinb" and self.distribution != "zinb":
+            return None
+        if x_batch is not None:
+            z = torch.cat([z, x_batch], dim=1)
+        if latent_lib is not None:
+            z = torch.cat([z, latent_lib], dim=1)
+        dec_h = self.dec_hidden(z)
+        out = self.output(dec_h)
+        tz = self.output_inverse_dispersion(dec_h)
+        pi = self.output_dropout(dec_h) if likelihood == "zinb" else None
+        if self.sample_factor == True:  # noqa: E712
+            assert lib is not None
+            L = lib
+        elif latent_lib is not None:
+            L = torch.exp(self.transformation_function(latent_lib))
+        else:
+            L = torch.ones(out.shape[0], dtype=out.dtype, device=out.device)
+        return ops.raw_rows_loss(out, pi, L, labels.to_dense() if hasattr(labels, "to_dense") else labels, tz)
+
     def forward(self, z, x_batch, lib, latent_lib):
         if x_batch is not None:
             z = torch.cat([z, x_batch], dim=1)

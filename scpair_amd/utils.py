@@ -199,6 +199,10 @@ def _vae_losses(input, lib, encoder, decoder, kl_weight, likelihood_type, add_co
     cov = input_batch if add_cov else None
     mu, sigma, z, latent_lib = encoder(input, cov)
     kl_divergence = encoder.last_kl
+    if likelihood_type in ("zinb", "nb") and hasattr(decoder, "fused_loss"):
+        recon = decoder.fused_loss(z, cov, lib, latent_lib, input, likelihood_type)
+        if recon is not None:
+            return kl_weight * kl_divergence + recon, recon, kl_divergence
     outputs = decoder(z, cov, lib, latent_lib)
     x = input.to_dense() if isinstance(input, BatchTiles) else input
     if likelihood_type in ("zinb", "nb"):
