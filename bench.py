@@ -253,7 +253,7 @@ def main():
         import pstats
         prof.disable()
         with open(os.environ["SCPAIR_BENCH_CPROFILE"], "w") as fh:
-            pstats.Stats(prof, stream=fh).sort_stats("cumulative").print_stats(70)
+            pstats.Stats(prof, stream=fh).sort_stats(os.environ.get("SCPAIR_BENCH_CPROFILE_SORT", "cumulative")).print_stats(70)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

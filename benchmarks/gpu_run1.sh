@@ -1,7 +1,3 @@
 set -e
-export TMPDIR=/tmp
-STEPS=30 timeout -k 10 120 python benchmarks/vae_c4.py 2>&1 | grep "VAE"
-STEPS=30 LIK=zinb timeout -k 10 120 python benchmarks/vae_c4.py 2>&1 | grep "VAE"
-rm -rf gpurun_out/prof_vae
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_vae -o vm -- python3 benchmarks/vae_c4.py > gpurun_out/vae_prof.log 2>&1
-grep "VAE" gpurun_out/vae_prof.log
+SCPAIR_BENCH_CPROFILE_SORT=tottime SCPAIR_BENCH_CPROFILE=gpurun_out/cprof_tot.txt timeout -k 10 200 python bench.py --gpus 1 --steps 30 --warmup 5 --cpu-steps 0 > gpurun_out/b_single.log 2>&1
+tail -1 gpurun_out/b_single.log | cut -c1-200
