@@ -5,9 +5,9 @@ The reference has no distributed code; the semantics imp
 single-process loop with the GLOBAL batch: every loss is a mean over label elements (loss.py:26, 39-40, 48, 50), so
 the global-batch gradient is sum_r (n_r / n_total) * g_r where n_r is rank r's number of valid label elements.
 
-Buckets: tensors >= `big` elements are reduced in place one by one (the wide first-layer dW is produced last in
-backward and is the only exposed message); everything smaller is packed into one flat buffer per call.  All
-collectives are issued async and waited together, so they overlap with whatever the caller runs in between.
+Buckets: tensors >= `big` elements (the wide first-layer dW, produced last in backward, the only exposed message)
+travel in one flat buffer (bf16 when `compress`), everything smaller in one fp32 buffer: two collectives per exchange,
+issued async and waited together, so they overlap with whatever the caller runs in between.
 """
 from __future__ import annotations
 
@@ -43,8 +43,11 @@ class GradSync:
             dist.broadcast(t.data if hasattr(t, "data") else t, src=src, group=self.group)
 
     def start_all_reduce(self, grads):
-        """Issue async SUM all-reduces for `grads` (list of tensors); returns nothing, call finish()."""
-        small = [g for g in grads if g.numel() < self.big]
+        """Issue async SUM all-reduces for `grads` (list of tensors); returns nothing, call finish().
+
+        Two buckets per call, each one collective: the wide tensors (>= `big` elements) packed into one flat buffer
+        (bf16 when `compress`), everything smaller packed into one fp32 buffer.  Packing and unpacking are one
+        multi-tensor copy each, so the host cost of an exchange does not grow with the number of tensors."""
         if self._backend != "nccl" and any(g.is_cuda for g in grads):
             # gloo with device tensors (one-GPU rehearsal of the N>1 path only): stage through host memory; gloo's
             # own device all-reduce stalls on this image
@@ -53,27 +56,28 @@ class GradSync:
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
                 g.copy_(h)
             return
-        async_ok = True
-        for g in grads:
-            if g.numel() >= self.big:
-                if self.compress:
-                    gb = g.to(torch.bfloat16).reshape(-1)
-                    self._pending.append((dist.all_reduce(gb, op=dist.ReduceOp.SUM, group=self.group, async_op=async_ok),
-                                          gb, [g]))
-                else:
-                    self._pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_ok),
-                                          None, None))
-        if small:
-            flat = torch.cat([g.reshape(-1) for g in small])
-            self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_ok), flat, small))
+        wide = [g for g in grads if g.numel() >= self.big]
+        small = [g for g in grads if g.numel() < self.big]
+        for bucket, dtype in ((wide, torch.bfloat16 if self.compress else torch.float32), (small, torch.float32)):
+            if not bucket:
+                continue
+            if len(bucket) == 1 and bucket[0].dtype == dtype and bucket[0].is_contiguous():
+                work = dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending.append((work, None, None))
+                continue
+            sizes = [g.numel() for g in bucket]
+            flat = torch.empty(sum(sizes), dtype=dtype, device=bucket[0].device)
+            torch._foreach_copy_(list(flat.split(sizes)), [g.reshape(-1) for g in bucket])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((work, flat, bucket))
 
     def finish(self):
-        for work, flat, small in self._pending:
+        for work, flat, bucket in self._pending:
             if work is not None:
                 work.wait()
             if flat is not None:
-                parts = flat.split([g.numel() for g in small])
-                torch._foreach_copy_(small, [p.view_as(g) for p, g in zip(parts, small)])
+                parts = flat.split([g.numel() for g in bucket])
+                torch._foreach_copy_(bucket, [p.view_as(g) for p, g in zip(parts, bucket)])
         self._pending = []
 
     def all_reduce_grads(self, params, n_valid):
