@@ -1,5 +1,5 @@
 set -e
-SCPAIR_BENCH_FORCE_DIST=1 timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 30 --warmup 5 --cpu-steps 0 > gpurun_out/b_rccl1.log 2>&1 || { tail -20 gpurun_out/b_rccl1.log; exit 1; }
-grep '^{"metric"' gpurun_out/b_rccl1.log | tail -1
-timeout -k 10 200 python bench.py --steps 30 --warmup 5 --cpu-steps 0 --no-fuse-opt > gpurun_out/b_nf.log 2>&1
-grep '^{"metric"' gpurun_out/b_nf.log | tail -1
+export TMPDIR=/tmp
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/t_all.log 2>&1 || { tail -40 gpurun_out/t_all.log; exit 1; }
+tail -2 gpurun_out/t_all.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -173,3 +173,45 @@ def test_run_with_input_transform():
     with pytest.raises(ValueError):
         S.scPair_object(scobj=None, modalities={"Gene Expression": "nb", "Peaks": "ber"}, save_model=False,
                         device=torch.device("cuda:0"), input_transform={"Gene Expression": "sqrt"})
+
+
+def test_augment_matches_reference():
+    """augment() (model.py:925-1036) from the reference's trained RNA encoder on extra unimodal cells, against the
+    four embedding tables and the fine-tuned encoder the reference produced (tests/golden/augment.npz,
+    tools/make_golden_augment.py).  Dropout 0 and BatchNorm on make the fine-tuning deterministic: the train-mode
+    batch statistics are the learning signal."""
+    import json
+    import os
+    import scipy.sparse as sp
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment.npz"))
+    c = json.loads(str(d["cfg"]))
+    data = synth.make_paired(c["n"], c["g"], c["p"], seed=c["seed"], p_atac=0.1)
+    dicts = []
+    for split in ("train", "val", "test"):
+        idx = data[split]
+        dicts.append({f"{nm}_{split}_{k}": (mat[idx] if k == "mtx" else None)
+                      for nm, mat in (("Gene Expression", data["rna"]), ("Peaks", data["atac"])) for k in ("mtx", "cov")})
+    obj = S.scPair_object(None, cov=None, modalities={"Gene Expression": "nb", "Peaks": "ber"}, SEED=0,
+                          hidden_layer=c["hidden"], dropout_rate=0.0, batchnorm=True, layernorm=True,
+                          batch_size=c["batch"], max_epochs=c["aug_epochs"], device=DEV, save_model=False, verbose=False)
+    obj.set_data(*dicts)
+    enc, _, _ = obj._build_predictor("Gene Expression", "Peaks", c["g"], c["p"], 0)
+    sd = {k[len("enc_trained/"):]: torch.tensor(d[k]) for k in d.files if k.startswith("enc_trained/")}
+    enc.load_state_dict(sd)
+    obj.encoder_dict = {"Gene Expression to Peaks": enc.eval()}
+    uni = sp.csr_matrix((d["uni/data"], d["uni/indices"], d["uni/indptr"]), shape=(c["n_uni"], c["g"]))
+    aug_d, aug_emb = obj.augment(type("Uni", (), {"X": uni})(), {"Gene Expression": "nb"})
+    assert list(aug_d.keys()) == [str(d["aug_key"])]
+    assert set(aug_emb.keys()) == {k[len("emb/"):] for k in d.files if k.startswith("emb/")}
+    for k, v in aug_emb.items():
+        ref = d["emb/" + k]
+        assert v.shape == ref.shape
+        assert float(np.abs(v - ref).max()) < 2e-3 * max(1.0, float(np.abs(ref).max())), k
+    for k, v in list(aug_d.values())[0].state_dict().items():
+        ref = torch.tensor(d["enc_augmented/" + k])
+        if ref.dtype.is_floating_point:
+            assert float((v.cpu() - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max())), k
+    # the fine-tuning moved the encoder away from the one it started from
+    moved = max(float((v.cpu() - sd[k]).abs().max()) for k, v in list(aug_d.values())[0].state_dict().items()
+                if sd[k].dtype.is_floating_point)
+    assert moved > 1e-3
