@@ -33,8 +33,10 @@ __global__ __launch_bounds__(256) void tiles_bounds_kernel(const int64_t* __rest
                                                            const int32_t* __restrict__ indices,
                                                            const int64_t* __restrict__ rows, int B, int sf, int nslice,
                                                            int32_t* __restrict__ bnd /* [B][nslice+1] */,
-                                                           int32_t* __restrict__ tot /* [ncb][nslice], zeroed */) {
+                                                           int32_t* __restrict__ tot /* [ncb][nslice], zeroed */,
+                                                           int32_t* __restrict__ nnan /* cleared here, counted later */) {
   int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && nnan) nnan[0] = 0;
   if (i >= B * (nslice + 1)) return;
   int b = i / (nslice + 1), sidx = i % (nslice + 1);
   int64_t r = rows[b];
@@ -258,17 +260,16 @@ extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, co
   int32_t* bnd = ws;
   int32_t* tot = ws + (long)B * (nslice + 1);
   SCP_HIP(hipMemsetAsync(tot, 0, (size_t)ncb * nslice * sizeof(int32_t), stream));
-  if (nnan) SCP_HIP(hipMemsetAsync(nnan, 0, sizeof(int32_t), stream));
   int nthr = B * (nslice + 1);
   hipLaunchKernelGGL(tiles_bounds_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, indptr, indices, rows, B, sf,
-                     nslice, bnd, tot);
+                     nslice, bnd, tot, nnan);
   SCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(tiles_scan_kernel, dim3(1), dim3(1024), 0, stream, tot, ncb * nslice, ptr + (long)ncb * F);
   SCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(tiles_place_kernel, dim3(nslice, ncb), dim3(256), 0, stream, indptr, indices, values, rows, B, F,
                      sf, nslice, bnd, tot, ptr, key, val);
   SCP_LAUNCH_CHECK();
-  if (lib || nnan) {
+  if (lib || (nnan && values)) {             // implicit ones cannot hold NaN: nothing to count
     hipLaunchKernelGGL(tiles_rowsum_kernel, dim3(B), dim3(256), 0, stream, indptr, values, rows, B, lib, nnan);
     SCP_LAUNCH_CHECK();
   }

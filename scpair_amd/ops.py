@@ -417,6 +417,14 @@ def _dec_ws(B, F, K, dev):
     return ws_f, ws_d
 
 
+def _scale_all(grads, g):
+    """grads *= g (the scalar upstream gradient of a fused loss) for every tensor of the list, in one multi-tensor
+    launch; the buffers are owned by the Function that produced them."""
+    ts = [t for t in grads if t is not None]
+    if ts:
+        torch._foreach_mul_(ts, g.reshape(()).to(ts[0].dtype))
+
+
 class BerDecoderLossFn(torch.autograd.Function):
     """loss = binarized_loss(y, sigmoid(h W^T + b) [* sigmoid(lrow)] [* sigmoid(fs)])  (model.py:164-190, loss.py:36-41)
     with dW, db, dh, dlrow, dfs produced by the same kernel pass."""
@@ -457,9 +465,9 @@ class BerDecoderLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dh, dW, db, dfs, dl = ctx.grads
         ctx.grads = None
-        sc = lambda t: None if t is None else t * g
-        dl_ = None if dl is None else (dl * g).reshape(ctx.lshape)
-        return sc(dh), sc(dW), sc(db), sc(dfs), dl_, None
+        _scale_all((dh, dW, db, dfs, dl), g)
+        dl_ = None if dl is None else dl.reshape(ctx.lshape)
+        return dh, dW, db, dfs, dl_, None
 
 
 def ber_decoder_loss(h, W, b, fs, lrow, tiles):
@@ -510,9 +518,9 @@ class NbDecoderLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dh, dW, db, dfs, dth, dlat = ctx.grads
         ctx.grads = None
-        sc = lambda t: None if t is None else t * g
-        dlat_ = None if dlat is None else (dlat * g).reshape(ctx.latshape)
-        return sc(dh), sc(dW), sc(db), sc(dfs), sc(dth), None, dlat_, None
+        _scale_all((dh, dW, db, dfs, dth, dlat), g)
+        dlat_ = None if dlat is None else dlat.reshape(ctx.latshape)
+        return dh, dW, db, dfs, dth, None, dlat_, None
 
 
 def nb_decoder_loss(h, W, b, fs, theta_param, lib_L, lat, tiles):
