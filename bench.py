@@ -48,6 +48,8 @@ def parse():
                     help="N > 1: all-reduce the wide first-layer gradients in fp32 even in bf16 mode (default: bf16)")
     ap.add_argument("--no-fuse-opt", action="store_true",
                     help="keep the AdamW step of the first-layer weights in the optimiser kernel (always so for N > 1)")
+    ap.add_argument("--no-grad-sink", action="store_true",
+                    help="N > 1, bf16 exchange: keep fp32 first-layer gradients + cast/copy instead of the bf16 exchange buffer")
     ap.add_argument("--zinb", action="store_true", help="C3: zero-inflated NB for RNA (the G x G dropout layer is live)")
     return ap.parse_args()
 
@@ -77,16 +79,21 @@ class Direction:
         self.first = [self.enc.hidden_rep[0].weight] + ([self.enc.hidden_lib[0][0].weight] if infer_lib else [])
         self.dist = out_dist
         self.fused = False
+        self.sink = None
         self.use_lib = sample_factor
         self.enc.train(); self.dec.train()
 
     def n_trained_params(self):
         """Parameters that received an update in the last step (dead layers get no gradient and are skipped)."""
-        fused = {id(p) for p in self.first} if self.fused else set()
-        return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None or id(p) in fused)
+        extra = {id(p) for p in self.first} if (self.fused or self.sink is not None) else set()
+        return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None or id(p) in extra)
 
-    def n_unfused_params(self):
-        return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None)
+    def adamw_kernel_bytes(self):
+        """Algorithmic bytes of this direction's multi-tensor AdamW launch: 28 B/param, 26 where the
+        gradient is read as bf16 from the exchange buffer; parameters updated inside their dW kernel are not in it."""
+        n32 = sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None)
+        n16 = sum(p.numel() for p in self.first) if self.sink is not None else 0
+        return 28.0 * n32 + 26.0 * n16
 
 
 def _raw_decoder(S, out_dim, hidden, sample_factor, zinb=False):
@@ -144,6 +151,8 @@ def main():
         sync = GradSync(compress=(a.precision == "bf16" and not a.fp32_exchange))
         for d_ in (A, Bd):
             sync.broadcast(list(d_.enc.parameters()) + list(d_.dec.parameters()))
+            if sync.compress and not a.no_grad_sink:
+                d_.sink = sync.make_sink(d_.first)     # dW of the wide first layers goes straight to the bf16 exchange buffer
 
     fuse = (sync is None) and (not a.no_fuse_opt) and a.precision == "bf16"
     if fuse:
@@ -172,7 +181,7 @@ def main():
         host_t["bwd"] += pc() - t1_
         params = [p for g in D.opt.param_groups for p in g["params"] if p.grad is not None]
         if sync is not None:
-            sync.start_all_reduce([p.grad for p in params])
+            sync.start_all_reduce([p.grad for p in params], sink=D.sink)
         return loss
 
     def finish_direction(D, time_adam):
@@ -188,7 +197,7 @@ def main():
             e0.record()
             D.opt.step(grad_scale=1.0 / world)
             e1.record()
-            adam_ev.append((e0, e1, D.n_unfused_params()))
+            adam_ev.append((e0, e1, D.adamw_kernel_bytes()))
         else:
             D.opt.step(grad_scale=1.0 / world)
 
@@ -268,7 +277,7 @@ def main():
     # moves 24 B/param of optimiser state (p, m, v read and written; the gradient stays on chip) + 2 B/param of bf16
     # shadow + its operands (tile-list entries, bf16 dY^T).  Timed with events around each launch on its stream.
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in adam_ev)
-    tot_bytes = sum(28.0 * n for _, _, n in adam_ev)
+    tot_bytes = sum(nb for _, _, nb in adam_ev)
     adam_gbs = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     n_params = A.n_trained_params() + Bd.n_trained_params()
     adam_roof = {"kernel": "adamw_kernel (fused multi-tensor AdamW)", "bound": "hbm", "achieved": adam_gbs,
@@ -318,7 +327,8 @@ def main():
                                f"batch {a.batch}/GPU, hidden {a.hidden}, dropout {a.dropout}, both directions per step",
                    "cells_resident_per_gpu": cells_here, "nnz_per_cell_rna": round(nnz_r, 1),
                    "nnz_per_cell_atac": round(nnz_a, 1), "precision": a.precision, "parallelism": f"dp{world}", "streams": a.streams,
-                   "grad_exchange": ("none" if sync is None else ("bf16 wide + fp32 rest" if sync.compress else "fp32")),
+                   "grad_exchange": ("none" if sync is None else (("bf16 wide (written by the dW kernel) + fp32 rest" if A.sink is not None
+                                                                    else "bf16 wide + fp32 rest") if sync.compress else "fp32")),
                    "optimizer": "AdamW; first-layer weights updated in their weight-gradient kernel" if fuse else "AdamW, one multi-tensor kernel",
                    "host_enqueue_ms_per_step": round(1e3 * t_host / a.steps, 3),
                    "host_enqueue_ms_by_phase": {k_: round(1e3 * v_ / a.steps, 3) for k_, v_ in host_t.items()},

@@ -60,6 +60,10 @@ int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int3
                       const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream);
 int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
                      const void* dYT, long ldt, float* dW, long ldw, void* stream);
+/* The same weight gradient written as bf16 [N][ldw] (data-parallel training in precision mode 'bf16': the kernel writes
+ * straight into the exchange buffer that the all-reduce sums and scp_adamw_multi then reads, g_bf16 = 1) */
+int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
+                         const void* dYT, long ldt, void* dW_bf16, long ldw, void* stream);
 /* The same weight gradient with the AdamW step of that weight (model.py:698-701, torch.optim.AdamW semantics as in
  * scp_adamw_multi) applied in the kernel's epilogue: W [N][ldw] fp32 master weights, exp_avg / exp_avg_sq (same
  * layout) and the bf16 shadow are updated in place and the gradient never reaches HBM.  For single-process training
@@ -190,6 +194,8 @@ typedef struct {
   float lr, weight_decay, bias_corr1, bias_corr2, grad_scale;
   void* p_bf16;      /* optional bf16 shadow of p laid out [n / cols][ld_bf16], rewritten with the new weights */
   long cols, ld_bf16;
+  long g_bf16;       /* != 0: g points to bf16 gradients (n contiguous elements: the data-parallel exchange buffer
+                        scp_spmm_dw_bf16_g16 writes and the all-reduce sums) instead of fp32 */
 } ScpAdamTensor;
 int scp_adamw_multi(const ScpAdamTensor* tensors /* host array */, int n, float beta1, float beta2, float eps,
                     void* stream);

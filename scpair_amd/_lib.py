@@ -26,7 +26,7 @@ U64 = C.c_uint64
 class AdamTensor(C.Structure):
     _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", L),
                 ("lr", F), ("weight_decay", F), ("bias_corr1", F), ("bias_corr2", F), ("grad_scale", F),
-                ("p_bf16", P), ("cols", L), ("ld_bf16", L)]
+                ("p_bf16", P), ("cols", L), ("ld_bf16", L), ("g_bf16", L)]
 
 
 _SIGS = {
@@ -45,6 +45,7 @@ _SIGS = {
     "scp_spmm_fwd_bf16_min_split": (I, [I]),
     "scp_spmm_fwd_bf16": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
     "scp_spmm_dw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
+    "scp_spmm_dw_bf16_g16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
     "scp_spmm_dw_adamw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P, P, P, L, F, F, F, F, F, F, F, F, P]),
     "scp_gemm_nt": (I, [I, I, I, P, L, L, P, L, L, P, L, P, I, I, I, P]),
     "scp_gemm_lib_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P]),

@@ -1,6 +1,6 @@
 // Fused multi-tensor AdamW (torch.optim.AdamW defaults as the reference uses them, model.py:698-701:
 // betas (0.9, 0.999), eps 1e-8, amsgrad False, decoupled decay p *= 1 - lr*wd).
-// HBM-bound: 16 B read (p, g, m, v) + 12 B written (p, m, v) per parameter = 28 B/param/step
+// HBM-bound: 16 B read (p, g, m, v; 14 B with bf16 gradients) + 12 B written (p, m, v) per parameter = 28 B/param/step
 // (+2 B/param for tensors that carry a bf16 shadow copy for the first-layer MFMA kernels).
 // Up to SCP_ADAM_MAX_TENSORS tensors per launch, descriptors passed by value (no host->device copy).
 #include "common.h"
@@ -24,7 +24,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
   long base = (long)(blk - pk.chunk_start[ti]) * ADAM_CHUNK;
   const AdamHyper hy = adam_hyper(t.lr, t.weight_decay, pk.beta1, pk.beta2, pk.eps, t.bias_corr1, t.bias_corr2,
                                   t.grad_scale);
-  bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
+  const bool g16 = t.g_bf16 != 0;
+  const __bf16* gh = (const __bf16*)t.g;
+  bool vec = ((((uintptr_t)t.p | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0) &&
+             (((uintptr_t)t.g & (g16 ? 7 : 15)) == 0);
+  auto gload = [&](long i) { return g16 ? (float)gh[i] : t.g[i]; };
   auto update = [&](float& p, float g, float& m, float& v) { adamw_update(hy, p, g, m, v); };
   auto shadow4 = [&](long i, const float (&pa)[4]) {
     __bf16* sh = (__bf16*)t.p_bf16;
@@ -51,7 +55,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
     for (int it = 0; it < 4; it++) {
       long i = base + (long)it * 1024 + threadIdx.x * 4;
       p[it] = __builtin_nontemporal_load((const f4*)(t.p + i));
-      g[it] = __builtin_nontemporal_load((const f4*)(t.g + i));
+      if (g16) {
+        bf16x4 gb = __builtin_nontemporal_load((const bf16x4*)(gh + i));
+        g[it] = f4{(float)gb[0], (float)gb[1], (float)gb[2], (float)gb[3]};
+      } else {
+        g[it] = __builtin_nontemporal_load((const f4*)(t.g + i));
+      }
       m[it] = __builtin_nontemporal_load((const f4*)(t.m + i));
       v[it] = __builtin_nontemporal_load((const f4*)(t.v + i));
     }
@@ -77,8 +86,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
     long i = base + (long)it * 1024 + threadIdx.x * 4;
     if (i >= t.n) break;
     if (vec && i + 4 <= t.n) {
-      float4 p = *(float4*)(t.p + i), g = *(const float4*)(t.g + i), m = *(float4*)(t.m + i), v = *(float4*)(t.v + i);
-      float pa[4] = {p.x, p.y, p.z, p.w}, ga[4] = {g.x, g.y, g.z, g.w}, ma[4] = {m.x, m.y, m.z, m.w},
+      float4 p = *(float4*)(t.p + i), m = *(float4*)(t.m + i), v = *(float4*)(t.v + i);
+      float pa[4] = {p.x, p.y, p.z, p.w}, ga[4] = {gload(i), gload(i + 1), gload(i + 2), gload(i + 3)}, ma[4] = {m.x, m.y, m.z, m.w},
             va[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; k++) update(pa[k], ga[k], ma[k], va[k]);
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
     } else {
       for (int k = 0; k < 4 && i + k < t.n; k++) {
         float p = t.p[i + k], m = t.m[i + k], v = t.v[i + k];
-        update(p, t.g[i + k], m, v);
+        update(p, gload(i + k), m, v);
         t.p[i + k] = p;
         if (t.p_bf16) {
           long rr = (i + k) / t.cols, cc = (i + k) - rr * t.cols;

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
 // Measured at C2 (900 x 100 k weights, 1024 cells): 556 us against 274 + 420 us for the two kernels; with a single
 // K-step the launch takes 457 us, i.e. the epilogue streams at 5.1 TB/s and most of the K loop hides behind it.
 // ------------------------------------------------------------------------------------------------------
-template <bool HASVAL, bool ADAM, int EPB = 16>
+template <bool HASVAL, bool ADAM, bool OUT16 = false, int EPB = 16>
 __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
   constexpr int EPT = HASVAL ? 4 : 2;             // sparse entries held per thread and stage
   constexpr int ASZ = 128 * LDK, BSZ = 256 * LDK;
@@ -468,7 +468,10 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           int m = m0 + wm * 64 + i2 * 32 + acc_row(e, lane);
-          if (m < g.N) g.C[(long)m * g.ldc + n] = acc[i2][jj][e];
+          if (m < g.N) {
+            if constexpr (OUT16) ((__bf16*)g.C)[(long)m * g.ldc + n] = (__bf16)acc[i2][jj][e];
+            else g.C[(long)m * g.ldc + n] = acc[i2][jj][e];
+          }
         }
       }
   } else {
@@ -684,6 +687,32 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
     hipLaunchKernelGGL((spmm_dw_bf16_kernel<true, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
   else
     hipLaunchKernelGGL((spmm_dw_bf16_kernel<false, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key,
+                                    const float* t_val, const void* dYT, long ldt, void* dW, long ldw, void* stream_) {
+  SCP_CHECK(ncells > 0 && N > 0 && F > 0, SCP_ERR_ARG, "scp_spmm_dw_bf16_g16: sizes must be positive");
+  SCP_CHECK(t_ptr && t_key && dYT && dW && ldw >= F, SCP_ERR_ARG, "scp_spmm_dw_bf16_g16: bad argument");
+  SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
+            "scp_spmm_dw_bf16_g16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
+  SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16_g16: more than %d cells per call unsupported",
+            64 * (PCH + 1));
+  static bool done_v = false, done_n = false;
+  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
+  int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true, false, true>, smem, &done_v)
+                 : set_smem((const void*)spmm_dw_bf16_kernel<false, false, true>, smem, &done_n);
+  if (rc) return rc;
+  SpArgs g = {};
+  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
+  g.D = (const __bf16*)dYT; g.ldd = ldt; g.C = (float*)dW; g.ldc = ldw;
+  g.tiles_m = (N + 127) / 128; g.tiles_n = (F + 255) / 256; g.nsplit = 1;
+  int grid = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
+  if (t_val)
+    hipLaunchKernelGGL((spmm_dw_bf16_kernel<true, false, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
+  else
+    hipLaunchKernelGGL((spmm_dw_bf16_kernel<false, false, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

@@ -231,7 +231,7 @@ def linear(x, W, b=None):
 # ------------------------------------------------------------------------------------------------
 class FcnnLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, cov, W, b, gamma, beta, slope, p_drop, seed, eps, shadow=None, fused=None):
+    def forward(ctx, x, cov, W, b, gamma, beta, slope, p_drop, seed, eps, shadow=None, fused=None, sink=None):
         """x: dense [B, F] tensor or BatchTiles; cov: dense [B, C] or None; W: [H, F + C];
         shadow: bf16 copy of W for the bf16 sparse kernels (or None); fused: FusedFirstLayer handle when the AdamW
         step of W runs inside the weight-gradient kernel (or None)."""
@@ -284,6 +284,7 @@ class FcnnLayerFn(torch.autograd.Function):
         ctx.cfg = (slope, p_drop, seed, Bn, H, F, C_, ns, b is not None)
         ctx.use_bf = use_bf
         ctx.fused = fused if (use_bf and C_ == 0 and Ftot % 4 == 0) else None
+        ctx.sink = sink if (use_bf and C_ == 0 and ctx.fused is None) else None
         return out
 
     @staticmethod
@@ -304,7 +305,7 @@ class FcnnLayerFn(torch.autograd.Function):
                                     _lib.ptr(dbeta), _lib.ptr(dbias), ws.data_ptr(), _lib.stream()), "scp_ln_act_bwd")
         dx = dW = None
         if ctx.needs_input_grad[2]:
-            if ctx.fused is None:
+            if ctx.fused is None and ctx.sink is None:
                 dW = torch.empty((H, Ftot), dtype=torch.float32, device=dev)
             if ctx.sparse and ctx.use_bf:
                 t = ctx.tiles
@@ -327,6 +328,13 @@ class FcnnLayerFn(torch.autograd.Function):
                     if tm is not None:
                         e1.record()
                         tm.append((e0, e1, H * Ftot, int(t.nnz) * (8 if t.val is not None else 4) + 2 * H * ldt))
+                elif ctx.sink is not None:
+                    # data parallel: dW goes to the exchange buffer as bf16; the optimiser reads it from there
+                    dW = None
+                    _lib.check(L.scp_spmm_dw_bf16_g16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                                                      dYT.data_ptr(), ldt, ctx.sink.view.data_ptr(), Ftot,
+                                                      _lib.stream()), "scp_spmm_dw_bf16_g16")
+                    ctx.sink.written = True
                 else:
                     _lib.check(L.scp_spmm_dw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
                                                   dYT.data_ptr(), ldt, dW.data_ptr(), Ftot, _lib.stream()),
@@ -345,17 +353,18 @@ class FcnnLayerFn(torch.autograd.Function):
         if (not ctx.sparse) and ctx.needs_input_grad[0]:
             dx = torch.empty((Bn, F), dtype=torch.float32, device=dev)
             gemm_nt_auto(Bn, F, H, dY, H, 1, W, 1, Ftot, dx, ns=ns)
-        return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None, None, None
+        return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
-    shadow = fused = None
+    shadow = fused = sink = None
     if isinstance(x, BatchTiles) and _ns() == 1 and W.is_cuda and W.dtype == torch.float32 and W.is_contiguous():
         shadow = shadow_of(W)
         if cov is None and torch.is_grad_enabled() and W.requires_grad:
             fused = fused_handle(W)
+            sink = grad_sink_of(W) if fused is None else None
     return FcnnLayerFn.apply(x, cov, W, b, gamma, beta, float(slope), float(p_drop), int(seed), float(eps), shadow,
-                             fused)
+                             fused, sink)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -724,6 +733,45 @@ class FusedFirstLayer:
 _fused = {}            # id(parameter) -> FusedFirstLayer
 
 
+class GradSink:
+    """bf16 exchange buffer of a first-layer weight under data parallelism (precision 'bf16'): the weight-gradient
+    kernel writes dW there as bf16, the all-reduce sums it in place and FusedAdamW reads it as the gradient, so the
+    fp32 gradient, its cast and the copy back never exist.  `view` is a contiguous bf16 [H, F] slice of the buffer
+    scpair_amd.distributed.GradSync reduces; `written` is set by backward and consumed by FusedAdamW.step."""
+
+    def __init__(self, param, view):
+        self._param, self.view, self.written = weakref.ref(param), view, False
+
+    @property
+    def param(self):
+        return self._param()
+
+
+_sinks = {}            # id(parameter) -> GradSink
+
+
+def set_grad_sink(W, view):
+    if view is None:
+        _sinks.pop(id(W), None)
+        return None
+    if view.dtype != torch.bfloat16 or tuple(view.shape) != tuple(W.shape) or not view.is_contiguous():
+        raise ValueError("gradient sink must be a contiguous bf16 tensor of the weight's shape")
+    for k in [k for k, h in _sinks.items() if h.param is None]:
+        del _sinks[k]
+    _sinks[id(W)] = GradSink(W, view)
+    return _sinks[id(W)]
+
+
+def grad_sink_of(W):
+    h = _sinks.get(id(W))
+    if h is None:
+        return None
+    if h.param is not W:
+        del _sinks[id(W)]
+        return None
+    return h
+
+
 def fused_handle(W):
     h = _fused.get(id(W))
     if h is None:
@@ -790,12 +838,17 @@ class FusedAdamW(torch.optim.Optimizer):
                     self.state[p]["step"] += 1
                     fz.pending = False
                     continue
+                g16 = 0
                 if p.grad is None:
-                    continue
+                    sk = _sinks.get(id(p)) if _sinks else None
+                    if sk is None or not sk.written or sk.param is not p:
+                        continue
+                    g, g16, sk.written = sk.view, 1, False      # bf16 gradient in the exchange buffer
+                else:
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 _lib.require_cuda(p)
                 if not p.is_contiguous():
                     raise RuntimeError("FusedAdamW needs contiguous parameters")
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = 0
@@ -807,7 +860,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 d = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                     p.numel(), group["lr"], group["weight_decay"], 1 - b1 ** t, 1 - b2 ** t, grad_scale,
                                     None if sh is None else sh.data_ptr(), p.shape[-1],
-                                    0 if sh is None else sh.shape[1])
+                                    0 if sh is None else sh.shape[1], g16)
                 by_hyper.setdefault((b1, b2, group["eps"]), []).append(d)
                 keep.append(g)
         for (b1, b2, eps), descs in by_hyper.items():

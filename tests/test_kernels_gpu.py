@@ -703,3 +703,49 @@ def test_vae_decoder_fused_loss_vs_oracle(S, lik, libmode):
         lg = pkg.loss.raw_loss(x=tiles.to_dense(), px_mu_rate=outs[2], px_theta=outs[1], px_mu_scale=outs[0],
                                px_pi=outs[3], likelihood=lik)
     close(lg, lo, rtol=5e-5, atol=0, what="generic path")
+
+
+@pytest.mark.parametrize("B,F,H,binary", [(300, 1000, 72, False), (512, 4100, 200, True)])
+def test_first_layer_wgrad_into_bf16_exchange_buffer(S, B, F, H, binary):
+    """Data-parallel path in precision 'bf16': scp_spmm_dw_bf16_g16 writes dW as bf16 into the exchange buffer and
+    scp_adamw_multi reads it from there (g_bf16) — against the fp32-gradient path with the gradient rounded to bf16
+    before the optimiser step (what the cast into the bf16 bucket and the copy back did)."""
+    ops = S.ops
+    ops.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(F + 2)
+        x = rand_csr(rng, B, F, 0.08, binary=binary)
+        tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(x, S.dev, binary=binary), np.arange(B))
+        g = torch.Generator().manual_seed(F)
+        W0 = torch.randn(H, F, generator=g) * 0.05
+        res = {}
+        for mode in ("plain", "sink"):
+            W = torch.nn.Parameter(W0.clone().to(S.dev))
+            opt = ops.FusedAdamW([W], lr=1e-2, weight_decay=1e-2)
+            sink = None
+            if mode == "sink":
+                buf = torch.zeros(H * F, dtype=torch.bfloat16, device=S.dev)
+                sink = ops.set_grad_sink(W, buf.view(H, F))
+            gd = torch.Generator(device=S.dev).manual_seed(7)
+            for step in range(3):
+                out = ops.fcnn_layer(tiles, None, W, None, None, None, 0.01)
+                dout = torch.randn(B, H, device=S.dev, generator=gd)
+                opt.zero_grad()
+                out.backward(dout)
+                if mode == "sink":
+                    assert W.grad is None and sink.written
+                    gref = res["plain_g"][step]
+                    assert torch.equal(sink.view, gref), "bf16 gradient in the exchange buffer"
+                else:
+                    res.setdefault("plain_g", []).append(W.grad.bfloat16())
+                    W.grad = W.grad.bfloat16().float()
+                opt.step(grad_scale=0.5)
+                if mode == "sink":
+                    assert not sink.written
+            st = opt.state[W]
+            res[mode] = [W.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()]
+            ops.set_grad_sink(W, None)
+        for nm, a, r_ in zip(("W", "exp_avg", "exp_avg_sq"), res["sink"], res["plain"]):
+            assert float((a - r_).abs().max()) <= 1e-6 * float(r_.abs().max()) + 1e-12, nm
+    finally:
+        ops.set_precision("fp32")
