@@ -16,7 +16,6 @@
 #include "scpair_hip.h"
 
 #define LDK 72
-#define PF 4   // sparse entries prefetched per thread per K-step
 #define PCH 255 // K-steps whose entry offsets are staged in LDS at a time
 
 struct SpArgs {
