@@ -98,3 +98,52 @@ def test_bf16_exchange_of_wide_gradients():
     assert np.abs(grads[0] - W1.grad.numpy()).max() > 0                                          # really compressed
     for ref, got in zip((b1, W2), grads[1:]):
         np.testing.assert_allclose(got, ref.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def _sink_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scpair_amd import ops
+    from scpair_amd.distributed import GradSync
+    sync = GradSync(big=1000, compress=True)
+    Wa = torch.nn.Parameter(torch.zeros(6, 40)); Wb = torch.nn.Parameter(torch.zeros(3, 40)); small = torch.nn.Parameter(torch.zeros(5))
+    flat, handles = sync.make_sink([Wa, Wb])
+    assert flat.dtype == torch.bfloat16 and flat.numel() == Wa.numel() + Wb.numel()
+    assert ops.grad_sink_of(Wa) is handles[0] and ops.grad_sink_of(Wb).view.shape == Wb.shape
+    # what the weight-gradient kernels do on the GPU: write this rank's bf16 dW into the views and flag them
+    handles[0].view.copy_(torch.full((6, 40), float(rank + 1)))
+    handles[1].view.copy_(torch.arange(120.0).reshape(3, 40) * (rank + 1))
+    handles[0].written = handles[1].written = True
+    small.grad = torch.full((5,), 0.5 * (rank + 1))
+    sync.start_all_reduce([small.grad], sink=(flat, handles))
+    sync.finish()
+    # a step in which no kernel wrote the buffer must not reduce it again
+    before = flat.clone()
+    handles[0].written = handles[1].written = False
+    sync.start_all_reduce([small.grad], sink=(flat, handles))
+    sync.finish()
+    if rank == 0:
+        out.put((handles[0].view.float().numpy(), handles[1].view.float().numpy(), small.grad.numpy(),
+                 bool(torch.equal(flat, before))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_exchange_buffer_written_by_the_kernels():
+    """GradSync.make_sink: the wide first-layer gradients live as bf16 in one flat exchange buffer that is all-reduced
+    in place with one collective (the GPU kernels write into its views; here the test does)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sink_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    a, b, s, untouched = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(a, np.full((6, 40), 3.0, dtype=np.float32))
+    np.testing.assert_allclose(b, np.arange(120.0).reshape(3, 40) * 3, rtol=2.0 ** -7)           # summed in bf16
+    np.testing.assert_allclose(s, np.full(5, 1.5 + 0.75 * 2))      # 0.5 + 1.0 summed once, then summed again (1.5 * 2)
+    assert untouched
