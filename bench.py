@@ -311,7 +311,8 @@ def main():
                 "launches_per_step": len(fused_ev) / max(a.steps, 1),
                 "other_params": adam_roof}
     else:
-        adam_roof["traffic"] = pmc_traffic("r01_adamw_traffic.json", 28.0 * n_params)
+        if A.sink is None:      # the counters were collected for fp32 gradients
+            adam_roof["traffic"] = pmc_traffic("r01_adamw_traffic.json", 28.0 * n_params)
         roof = adam_roof
 
     out = {

@@ -145,7 +145,7 @@ def _pick_split(M, N, K):
 # ------------------------------------------------------------------------------------------------
 # Linear (dense):  y = x W^T + b
 # ------------------------------------------------------------------------------------------------
-_LIB_GEMM_MIN = 1 << 30      # M*N*K from which a plain nn.Linear goes to the library bf16 GEMM (precision 'bf16' only)
+_LIB_GEMM_MIN = 1 << 29      # M*N*K from which a plain nn.Linear goes to the library bf16 GEMM (precision 'bf16' only)
 
 
 def cast_bf16(x, rows, cols):

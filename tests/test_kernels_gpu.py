@@ -448,7 +448,7 @@ def test_bf16_shadow_tracks_weights(S):
 
 
 def test_linear_library_gemm_bf16(S):
-    """Wide plain nn.Linear in bf16 mode (M*N*K >= 2^30: ZINB G x G layer, VAE 900<->G layers) runs on the library
+    """Wide plain nn.Linear in bf16 mode (M*N*K >= 2^29: ZINB G x G layer, VAE 900<->G layers) runs on the library
     bf16 GEMM behind scp_gemm_lib_bf16: forward, dgrad, wgrad and bias gradient against fp64 matmuls of the
     bf16-rounded operands; the shadow stays equal to bf16(W) across a FusedAdamW step."""
     S.ops.set_precision("bf16")
