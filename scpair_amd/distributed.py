@@ -38,6 +38,17 @@ class GradSync:
         return np.array_split(rows, self.world)[self.rank]
 
     # -- collectives -----------------------------------------------------------------------------------------
+    def _sum(self, t):
+        """Blocking SUM all-reduce of a small tensor, in place.  Backends other than nccl get device tensors through
+        host memory (gloo's own device all-reduce stalls on this image; gloo + GPU is the one-GPU rehearsal only)."""
+        if self._backend != "nccl" and t.is_cuda:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
     def broadcast(self, tensors, src=0):
         for t in tensors:
             dist.broadcast(t.data if hasattr(t, "data") else t, src=src, group=self.group)
@@ -101,8 +112,7 @@ class GradSync:
         """Global-batch gradient: each rank scales its mean-gradient by n_r / n_total, then SUM all-reduce."""
         dev = params[0].device
         nv = torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(1).clone()
-        tot = nv.clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        tot = self._sum(nv.clone())
         w = (nv / tot).to(torch.float32)
         grads = [p.grad for p in params if p.grad is not None]
         for g in grads:
@@ -114,10 +124,9 @@ class GradSync:
         dev = value.device
         v = torch.stack([value.double() * torch.as_tensor(n_valid, dtype=torch.float64, device=dev),
                          torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(())])
-        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(v)
         return (v[0] / v[1]).to(value.dtype)
 
     def reduce_scalars(self, num, den):
-        v = torch.stack([num.double(), den.double()])
-        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        v = self._sum(torch.stack([num.double(), den.double()]))
         return v[0], v[1]
