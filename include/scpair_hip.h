@@ -89,6 +89,13 @@ int scp_slab_reduce(const float* slabs, long slab_stride, int nslab, int rows, i
 int scp_colsum(const float* X, long ld, int rows, int cols, float* out, float* partials_ws /* [32*cols] */,
                void* stream);
 
+/* scp_colsum without a caller workspace and without any allocation.  No counterpart in the reference: it is for callers
+ * that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The
+ * [32][cols] partial sums live in a device array inside the library (2 MiB per GPU, held until the process ends), so
+ * cols <= scp_colsum_noalloc_max_cols() (16384; SCP_ERR_SHAPE beyond).  Calls that overlap on one GPU race on it. */
+int scp_colsum_noalloc_max_cols(void);
+int scp_colsum_noalloc(const float* X, long ld, int rows, int cols, float* out, void* stream);
+
 /* ---- FCNN layer epilogue: [LayerNorm] -> LeakyReLU(slope)/ReLU(0) -> Dropout (utils.py:58-63),
  *      fused with the split-K slab reduction and the bias add; gamma/beta null = no LayerNorm ---- */
 int scp_ln_act_fwd(const float* Y, long ldy, long slab_stride, int nslab, const float* bias, const float* gamma,

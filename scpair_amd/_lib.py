@@ -51,6 +51,8 @@ _SIGS = {
     "scp_gemm_lib_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P]),
     "scp_slab_reduce": (I, [P, L, I, I, I, L, P, P, L, P]),
     "scp_colsum": (I, [P, L, I, I, P, P, P]),
+    "scp_colsum_noalloc_max_cols": (I, []),
+    "scp_colsum_noalloc": (I, [P, L, I, I, P, P]),
     "scp_bn_fwd": (I, [P, L, I, I, P, P, P, P, I, F, F, F, U64, P, P, P, L, P]),
     "scp_bn_bwd": (I, [P, L, P, L, I, I, P, P, P, I, F, U64, P, L, P, P, P]),
     "scp_ln_act_fwd": (I, [P, L, L, I, P, P, P, I, I, F, F, F, U64, P, L, P, P, L, P]),

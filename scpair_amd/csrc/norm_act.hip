@@ -5,6 +5,8 @@
 // A row lives in registers, so the forward reads the slabs once and writes xhat + out once, the backward
 // reads dOut + xhat once and writes dY once.  Narrow rows (H <= 64) use one wave per row; wider rows use
 // one 256-thread workgroup per row (16 waves per CU at batch 1024, several slab loads in flight per lane).
+#include <mutex>
+
 #include "common.h"
 #include "scpair_hip.h"
 
@@ -440,6 +442,44 @@ extern "C" int scp_colsum(const float* X, long ld, int rows, int cols, float* ou
                      out, (float*)nullptr, (float*)nullptr);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
+}
+
+// scp_colsum for callers that cannot allocate (HIP graph capture, serving loops): the [32][cols] partial sums live
+// in a file-scope device array instead of a caller workspace.  `scratch` is a host-side stand-in for the symbol; its
+// device address is looked up once per device (each GPU holds its own copy) and only that address is ever passed to
+// kernels.  Every slot that the reduction reads is rewritten by the partial kernel of the same call, so nothing has
+// to be cleared between calls; two calls that overlap on one GPU (different streams) would race on the array.
+#define SCP_COLSUM_NOALLOC_MAX_COLS 16384
+static __device__ __align__(256) float scratch[32 * SCP_COLSUM_NOALLOC_MAX_COLS];      // 2 MiB per GPU
+static float* g_scratch_ptr[64] = {nullptr};
+static std::mutex g_scratch_mu;
+
+static int colsum_scratch(float** out) {
+  int dev = -1;
+  SCP_HIP(hipGetDevice(&dev));
+  SCP_CHECK(dev >= 0 && dev < 64, SCP_ERR_ARG, "scp_colsum_noalloc: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    SCP_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    SCP_CHECK(p != nullptr, SCP_ERR_HIP, "scp_colsum_noalloc: null symbol address");
+    g_scratch_ptr[dev] = (float*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return SCP_OK;
+}
+
+extern "C" int scp_colsum_noalloc_max_cols(void) { return SCP_COLSUM_NOALLOC_MAX_COLS; }
+
+extern "C" int scp_colsum_noalloc(const float* X, long ld, int rows, int cols, float* out, void* stream_) {
+  SCP_CHECK(X && out && rows > 0 && cols > 0, SCP_ERR_ARG, "scp_colsum_noalloc: bad argument");
+  SCP_CHECK(cols <= SCP_COLSUM_NOALLOC_MAX_COLS, SCP_ERR_SHAPE,
+            "scp_colsum_noalloc: cols=%d exceeds the built-in workspace (max %d columns); use scp_colsum with a "
+            "caller workspace", cols, SCP_COLSUM_NOALLOC_MAX_COLS);
+  float* ws = nullptr;
+  int rc = colsum_scratch(&ws);
+  if (rc) return rc;
+  return scp_colsum(X, ld, rows, cols, out, ws, stream_);
 }
 
 // ---- BatchNorm1d (training statistics / running statistics) + dropout --------------------------------------------
