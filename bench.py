@@ -29,8 +29,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cells", type=int, default=100_000)
     ap.add_argument("--genes", type=int, default=20_000)
     ap.add_argument("--peaks", type=int, default=100_000)
@@ -51,6 +51,12 @@ def parse():
     ap.add_argument("--no-grad-sink", action="store_true",
                     help="N > 1, bf16 exchange: keep fp32 first-layer gradients + cast/copy instead of the bf16 exchange buffer")
     ap.add_argument("--zinb", action="store_true", help="C3: zero-inflated NB for RNA (the G x G dropout layer is live)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N = 1: replay the step as one HIP graph (scpair_amd.graph.CapturedStep) instead of issuing every "
+                         "launch from the host.  Off by default: on ROCm 7.2 a graph with two forked streams is replayed "
+                         "node by node at the eager host cost, and the linear (one stream) replay took a box down")
+    ap.add_argument("--roofline-steps", type=int, default=20,
+                    help="untimed single-stream steps after the timed region whose per-launch HIP events give roofline.achieved")
     return ap.parse_args()
 
 
@@ -201,17 +207,16 @@ def main():
         else:
             D.opt.step(grad_scale=1.0 / world)
 
-    def step(time_adam=False):
+    def next_rows():
         if state["cur"] + a.batch > cells_here:
             state["perm"], state["cur"] = rng.permutation(cells_here), 0
             state["perm_dev"] = torch.from_numpy(state["perm"]).to(dev)        # one upload per epoch
         rows = state["perm"][state["cur"]:state["cur"] + a.batch]
         rows_dev = state["perm_dev"][state["cur"]:state["cur"] + a.batch]
         state["cur"] += a.batch
-        t0_ = pc()
-        t_rna = S.BatchTiles(rna, rows_dev, want_lib=True, rows_host=rows)
-        t_atac = S.BatchTiles(atac, rows_dev, want_lib=False, rows_host=rows)
-        host_t["tiles"] += pc() - t0_
+        return rows, rows_dev
+
+    def both_directions(t_rna, t_atac, time_adam, side):
         if side is None:
             la = one_direction(A, t_rna, t_atac, time_adam)
             finish_direction(A, time_adam)
@@ -219,8 +224,7 @@ def main():
             finish_direction(Bd, time_adam)
             return la, lb
         # the two predictors share nothing but the minibatch: one stream each, both after the tile-list build
-        ev = torch.cuda.Event()
-        ev.record()
+        cur = torch.cuda.current_stream()
         for t in (t_rna, t_atac):
             for x in (t.ptr, t.key, t.val, t.lib, t.nnan, t.rows):
                 if x is not None:
@@ -228,36 +232,73 @@ def main():
                         x.record_stream(st)
         out = []
         for st, (D, tx, ty) in zip(side, ((A, t_rna, t_atac), (Bd, t_atac, t_rna))):
+            st.wait_stream(cur)
             with torch.cuda.stream(st):
-                st.wait_event(ev)
                 out.append(one_direction(D, tx, ty, time_adam))
                 finish_direction(D, time_adam)
+        for st in side:
+            cur.wait_stream(st)
         return out[0], out[1]
 
+    def step(time_adam=False, side_=None):
+        rows, rows_dev = next_rows()
+        t0_ = pc()
+        t_rna = S.BatchTiles(rna, rows_dev, want_lib=True, rows_host=rows)
+        t_atac = S.BatchTiles(atac, rows_dev, want_lib=False, rows_host=rows)
+        host_t["tiles"] += pc() - t0_
+        return both_directions(t_rna, t_atac, time_adam, side_)
+
     side = (torch.cuda.Stream(), torch.cuda.Stream()) if a.streams == 2 else None
+
+    # ---- the whole paired step as one HIP graph (N = 1): fixed-capacity tile lists, device-resident per-step words ----
+    # Under rocprofv3 the step is issued eagerly: the kernels and their order are the same, and a graph replay under
+    # the profiler's queue interception took a box down once this round (the only difference from runs that passed).
+    under_profiler = any(k_ in os.environ for k_ in ("ROCPROFILER_LIBRARY_CTOR", "ROCPROF_OUTPUT_PATH"))
+    use_graph = (sync is None) and a.graph and not under_profiler
+    captured = None
+    if use_graph:
+        from scpair_amd.graph import CapturedStep
+        cap_r, cap_a = rna.max_batch_nnz(a.batch), atac.max_batch_nnz(a.batch)
+
+        def graph_fn(rows_buf):
+            t_rna = S.BatchTiles(rna, rows_buf, want_lib=True, capacity=cap_r)
+            t_atac = S.BatchTiles(atac, rows_buf, want_lib=False, capacity=cap_a)
+            return both_directions(t_rna, t_atac, False, side)
+
+        captured = CapturedStep(graph_fn, [A.opt, Bd.opt], a.batch, dev)
+
+    def graph_step():
+        _, rows_dev = next_rows()
+        return captured(rows_dev)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for _ in range(max(a.warmup, 2) if use_graph else a.warmup):
+        step(side_=side)
+    if use_graph:
+        barrier()
+        captured.capture(next_rows()[1])
+        for _ in range(3):
+            graph_step()
     barrier()
     prof = None
     if os.environ.get("SCPAIR_BENCH_CPROFILE") and rank == 0:      # diagnostic: where the host enqueue time goes
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
-    if fuse:
-        S.ops.set_fused_timer(fused_ev)
     for k_ in host_t:
         host_t[k_] = 0.0
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        la, lb = step(time_adam=True)
+    if use_graph:
+        for _ in range(a.steps):
+            la, lb = graph_step()
+    else:
+        for _ in range(a.steps):
+            la, lb = step(side_=side)
     t_host = time.perf_counter() - t0             # host enqueue time of the timed steps (diagnostic)
-    S.ops.set_fused_timer(None)
     if prof is not None:
         import pstats
         prof.disable()
@@ -270,6 +311,29 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     losses = (float(la.detach()), float(lb.detach()))
+    # host cost of issuing ONE step into an idle queue (the run-ahead figure above includes time blocked on a full queue)
+    t_issue = 0.0
+    for _ in range(10):
+        torch.cuda.synchronize()
+        t1_ = time.perf_counter()
+        if use_graph:
+            graph_step()
+        else:
+            step(side_=side)
+        t_issue += time.perf_counter() - t1_
+    barrier()
+    host_by_phase = {k_: round(1e3 * v_ / a.steps, 3) for k_, v_ in host_t.items()}
+
+    # ---- roofline pass (untimed): the same step issued eagerly on ONE stream, HIP events around every launch of the
+    # dominant kernel on that stream, so the durations hold no time queued behind the other direction's kernels and
+    # agree with rocprofv3's per-kernel durations of this command (profiles/) ----
+    if fuse:
+        S.ops.set_fused_timer(fused_ev)
+    for _ in range(a.roofline_steps if world == 1 else 0):
+        step(time_adam=True, side_=None)
+    S.ops.set_fused_timer(None)
+    barrier()
+    n_roof = max(a.roofline_steps, 1)
 
     # ---- roofline of the dominant kernel ------------------------------------------------------------------------
     # Two-kernel path (--no-fuse-opt, N > 1): the multi-tensor AdamW kernel, 28 B/param.
@@ -282,8 +346,8 @@ def main():
     n_params = A.n_trained_params() + Bd.n_trained_params()
     adam_roof = {"kernel": "adamw_kernel (fused multi-tensor AdamW)", "bound": "hbm", "achieved": adam_gbs,
                  "peak": 8000.0, "unit": "GB/s", "frac": adam_gbs / 8000.0, "traffic": None,
-                 "algorithmic_bytes_per_launch_set": tot_bytes / max(a.steps, 1),
-                 "avg_ms_per_step_in_kernel": tot_ms / max(a.steps, 1)}
+                 "algorithmic_bytes_per_launch_set": tot_bytes / n_roof,
+                 "avg_ms_per_step_in_kernel": tot_ms / n_roof}
 
     def pmc_traffic(name, want_bytes):
         # HBM bytes of the kernel from PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes over
@@ -305,10 +369,12 @@ def main():
         f_gbs = f_bytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
         roof = {"kernel": "spmm_dw_bf16_kernel<*, ADAM> (first-layer weight gradient with the AdamW step in its epilogue)",
                 "bound": "hbm", "achieved": f_gbs, "peak": 8000.0, "unit": "GB/s", "frac": f_gbs / 8000.0,
-                "traffic": pmc_traffic("r01_dw_adamw_traffic.json", f_bytes / max(a.steps, 1)),
-                "algorithmic_bytes_per_launch_set": f_bytes / max(a.steps, 1),
-                "avg_ms_per_step_in_kernel": f_ms / max(a.steps, 1),
-                "launches_per_step": len(fused_ev) / max(a.steps, 1),
+                "traffic": pmc_traffic("r01_dw_adamw_traffic.json", f_bytes / n_roof),
+                "traffic_source": "stored: profiles/r01_dw_adamw_traffic.json (separate rocprofv3 --pmc passes over this command)",
+                "algorithmic_bytes_per_launch_set": f_bytes / n_roof,
+                "avg_ms_per_step_in_kernel": f_ms / n_roof,
+                "launches_per_step": len(fused_ev) / n_roof,
+                "timing": f"HIP events around each launch, {n_roof} eager single-stream steps after the timed region",
                 "other_params": adam_roof}
     else:
         if A.sink is None:      # the counters were collected for fp32 gradients
@@ -331,8 +397,10 @@ def main():
                    "grad_exchange": ("none" if sync is None else (("bf16 wide (written by the dW kernel) + fp32 rest" if A.sink is not None
                                                                     else "bf16 wide + fp32 rest") if sync.compress else "fp32")),
                    "optimizer": "AdamW; first-layer weights updated in their weight-gradient kernel" if fuse else "AdamW, one multi-tensor kernel",
-                   "host_enqueue_ms_per_step": round(1e3 * t_host / a.steps, 3),
-                   "host_enqueue_ms_by_phase": {k_: round(1e3 * v_ / a.steps, 3) for k_, v_ in host_t.items()},
+                   "host_enqueue_ms_per_step": round(1e3 * t_issue / 10, 3),
+                   "host_loop_ms_per_step": round(1e3 * t_host / a.steps, 3),
+                   "host_enqueue_ms_by_phase": host_by_phase,
+                   "step_issue": "HIP graph replay (rows copy + per-step words + hipGraphLaunch)" if use_graph else ("eager launches (profiler attached)" if under_profiler else "eager launches"),
                    "trained_params": n_params, "final_losses": losses},
         "roofline": roof,
     }

@@ -72,7 +72,9 @@ int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_ptr, const i
 int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
                            const void* dYT, long ldt, float* W, long ldw, float* exp_avg, float* exp_avg_sq,
                            void* W_bf16, long ld_bf16, float lr, float weight_decay, float beta1, float beta2, float eps,
-                           float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+                           float bias_corr1, float bias_corr2, float grad_scale,
+                           const float* bc_dev /* nullable: device {bias_corr1, bias_corr2} used instead of the values */,
+                           void* stream);
 
 /* ---- dense layers: nn.Linear forward / dgrad / wgrad (utils.py:57; model.py:84, 92, 163, 217, 228,
  *      280, 331; pairedVAE.py:49-50, 111-119) as one strided GEMM  C[M,N] (+)= A[M,K] B[N,K]^T + bias ---- */
@@ -100,20 +102,24 @@ int scp_colsum_noalloc(const float* X, long ld, int rows, int cols, float* out, 
  *      fused with the split-K slab reduction and the bias add; gamma/beta null = no LayerNorm ---- */
 int scp_ln_act_fwd(const float* Y, long ldy, long slab_stride, int nslab, const float* bias, const float* gamma,
                    const float* beta, int B, int H, float eps, float slope, float p_drop, uint64_t seed,
+                   const uint64_t* seed_dev /* nullable: device word added to seed (scp_step_state_set) */,
                    float* xhat /* [B][ldx] saved for backward, nullable */, long ldx, float* rstd /* [B] */,
                    float* out, long ldo, void* stream);
 /* BatchNorm1d (placed after the activation, utils.py:61-62) + the layer's Dropout: batch statistics (training:
  * biased variance for the output, unbiased for the running estimate, momentum update in place) or running statistics
  * (eval); save_mean / save_rstd [H] feed the backward */
 int scp_bn_fwd(const float* x, long ldx, int B, int H, const float* gamma, const float* beta, float* run_mean,
-               float* run_var, int training, float momentum, float eps, float p_drop, uint64_t seed, float* save_mean,
+               float* run_var, int training, float momentum, float eps, float p_drop, uint64_t seed,
+               const uint64_t* seed_dev, float* save_mean,
                float* save_rstd, float* y, long ldy, void* stream);
 int scp_bn_bwd(const float* dy, long lddy, const float* x, long ldx, int B, int H, const float* gamma,
-               const float* save_mean, const float* save_rstd, int training, float p_drop, uint64_t seed, float* dx,
+               const float* save_mean, const float* save_rstd, int training, float p_drop, uint64_t seed,
+               const uint64_t* seed_dev, float* dx,
                long lddx, float* dgamma, float* dbeta, void* stream);
 int scp_ln_act_bwd_grid(int B);   /* partials_ws needs grid*3*H floats */
 int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, long ldx, const float* rstd, const float* gamma,
-                   const float* beta, int B, int H, float slope, float p_drop, uint64_t seed, float* dY, long ldy,
+                   const float* beta, int B, int H, float slope, float p_drop, uint64_t seed, const uint64_t* seed_dev,
+                   float* dY, long ldy,
                    float* dgamma, float* dbeta, float* dbias /* each [H], nullable */, float* partials_ws,
                    void* stream);
 
@@ -203,9 +209,15 @@ typedef struct {
   long cols, ld_bf16;
   long g_bf16;       /* != 0: g points to bf16 gradients (n contiguous elements: the data-parallel exchange buffer
                         scp_spmm_dw_bf16_g16 writes and the all-reduce sums) instead of fp32 */
+  const float* bc_dev; /* nullable: device words {bias_corr1, bias_corr2} read instead of the two values above */
 } ScpAdamTensor;
 int scp_adamw_multi(const ScpAdamTensor* tensors /* host array */, int n, float beta1, float beta2, float eps,
                     void* stream);
+/* Per-step state of a training step captured in a HIP graph (no counterpart in the reference, whose step is eager:
+ * utils.py:118-148).  A graph bakes by-value kernel arguments; what changes per step -- the dropout seed and AdamW's
+ * bias corrections 1 - beta^t -- is read from 16 bytes of device memory {uint64 seed_offset; float bc1; float bc2}
+ * (the seed_dev / bc_dev arguments above point into it) that this call rewrites before each replay. */
+int scp_step_state_set(void* state, uint64_t seed_offset, float bias_corr1, float bias_corr2, void* stream);
 
 #ifdef __cplusplus
 }

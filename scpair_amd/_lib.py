@@ -26,7 +26,7 @@ U64 = C.c_uint64
 class AdamTensor(C.Structure):
     _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", L),
                 ("lr", F), ("weight_decay", F), ("bias_corr1", F), ("bias_corr2", F), ("grad_scale", F),
-                ("p_bf16", P), ("cols", L), ("ld_bf16", L), ("g_bf16", L)]
+                ("p_bf16", P), ("cols", L), ("ld_bf16", L), ("g_bf16", L), ("bc_dev", P)]
 
 
 _SIGS = {
@@ -46,18 +46,18 @@ _SIGS = {
     "scp_spmm_fwd_bf16": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
     "scp_spmm_dw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
     "scp_spmm_dw_bf16_g16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
-    "scp_spmm_dw_adamw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P, P, P, L, F, F, F, F, F, F, F, F, P]),
+    "scp_spmm_dw_adamw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P, P, P, L, F, F, F, F, F, F, F, F, P, P]),
     "scp_gemm_nt": (I, [I, I, I, P, L, L, P, L, L, P, L, P, I, I, I, P]),
     "scp_gemm_lib_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P]),
     "scp_slab_reduce": (I, [P, L, I, I, I, L, P, P, L, P]),
     "scp_colsum": (I, [P, L, I, I, P, P, P]),
     "scp_colsum_noalloc_max_cols": (I, []),
     "scp_colsum_noalloc": (I, [P, L, I, I, P, P]),
-    "scp_bn_fwd": (I, [P, L, I, I, P, P, P, P, I, F, F, F, U64, P, P, P, L, P]),
-    "scp_bn_bwd": (I, [P, L, P, L, I, I, P, P, P, I, F, U64, P, L, P, P, P]),
-    "scp_ln_act_fwd": (I, [P, L, L, I, P, P, P, I, I, F, F, F, U64, P, L, P, P, L, P]),
+    "scp_bn_fwd": (I, [P, L, I, I, P, P, P, P, I, F, F, F, U64, P, P, P, P, L, P]),
+    "scp_bn_bwd": (I, [P, L, P, L, I, I, P, P, P, I, F, U64, P, P, L, P, P, P]),
+    "scp_ln_act_fwd": (I, [P, L, L, I, P, P, P, I, I, F, F, F, U64, P, P, L, P, P, L, P]),
     "scp_ln_act_bwd_grid": (I, [I]),
-    "scp_ln_act_bwd": (I, [P, L, P, L, P, P, P, I, I, F, F, U64, P, L, P, P, P, P, P]),
+    "scp_ln_act_bwd": (I, [P, L, P, L, P, P, P, I, I, F, F, U64, P, P, L, P, P, P, P, P]),
     "scp_dec_chunks": (I, [I]),
     "scp_dec_kp": (I, [I]),
     "scp_dec_ws_floats": (L, [I, I, I]),
@@ -78,6 +78,7 @@ _SIGS = {
     "scp_raw_rows_bwd": (I, [P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, P, L, P, L, P, L, P, P]),
     "scp_fos_counts": (I, [P, L, P, L, I, I, P, P, P, P, P]),
     "scp_adamw_multi": (I, [C.POINTER(AdamTensor), I, F, F, F, P]),
+    "scp_step_state_set": (I, [P, U64, F, F, P]),
 }
 
 EXPORTS = tuple(_SIGS)

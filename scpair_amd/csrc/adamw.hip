@@ -22,8 +22,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
   while (ti + 1 < pk.n && blk >= pk.chunk_start[ti + 1]) ti++;
   const ScpAdamTensor t = pk.t[ti];
   long base = (long)(blk - pk.chunk_start[ti]) * ADAM_CHUNK;
-  const AdamHyper hy = adam_hyper(t.lr, t.weight_decay, pk.beta1, pk.beta2, pk.eps, t.bias_corr1, t.bias_corr2,
-                                  t.grad_scale);
+  // bias corrections: by value, or (HIP-graph replays) read from the device words scp_step_state_set rewrites per step
+  const float bc1 = t.bc_dev ? t.bc_dev[0] : t.bias_corr1, bc2 = t.bc_dev ? t.bc_dev[1] : t.bias_corr2;
+  const AdamHyper hy = adam_hyper(t.lr, t.weight_decay, pk.beta1, pk.beta2, pk.eps, bc1, bc2, t.grad_scale);
   const bool g16 = t.g_bf16 != 0;
   const __bf16* gh = (const __bf16*)t.g;
   bool vec = ((((uintptr_t)t.p | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0) &&
@@ -115,18 +116,20 @@ extern "C" int scp_adamw_multi(const ScpAdamTensor* tensors, int n, float beta1,
                                void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(tensors && n > 0, SCP_ERR_ARG, "scp_adamw_multi: no tensors");
-  for (int o = 0; o < n; o += SCP_ADAM_MAX_TENSORS) {
+  int i = 0;                                 // input cursor, carried across launches (zero-size tensors take no slot)
+  while (i < n) {
     AdamPack pk;
     pk.n = 0;
     pk.beta1 = beta1; pk.beta2 = beta2; pk.eps = eps;
     int chunks = 0;
-    for (int i = o; i < n && pk.n < SCP_ADAM_MAX_TENSORS; i++) {
+    for (; i < n && pk.n < SCP_ADAM_MAX_TENSORS; i++) {
       const ScpAdamTensor& t = tensors[i];
       SCP_CHECK(t.p && t.g && t.m && t.v, SCP_ERR_ARG, "scp_adamw_multi: null pointer in tensor %d", i);
       SCP_CHECK(t.n >= 0, SCP_ERR_ARG, "scp_adamw_multi: negative size in tensor %d", i);
       SCP_CHECK(!t.p_bf16 || (t.cols > 0 && t.ld_bf16 >= t.cols && t.ld_bf16 % 8 == 0), SCP_ERR_ARG,
                 "scp_adamw_multi: bad bf16 shadow geometry in tensor %d", i);
-      SCP_CHECK(t.bias_corr1 > 0.f && t.bias_corr2 > 0.f, SCP_ERR_ARG, "scp_adamw_multi: bias corrections must be > 0");
+      SCP_CHECK(t.bc_dev || (t.bias_corr1 > 0.f && t.bias_corr2 > 0.f), SCP_ERR_ARG,
+                "scp_adamw_multi: bias corrections must be > 0");
       if (t.n == 0) continue;
       pk.t[pk.n] = t;
       pk.chunk_start[pk.n] = chunks;
@@ -138,5 +141,25 @@ extern "C" int scp_adamw_multi(const ScpAdamTensor* tensors, int n, float beta1,
     hipLaunchKernelGGL(adamw_kernel, dim3(chunks), dim3(256), 0, stream, pk);
     SCP_LAUNCH_CHECK();
   }
+  return SCP_OK;
+}
+
+// ---- per-step state for HIP-graph replays ---------------------------------------------------------------------
+// state: 16 bytes of device memory = { uint64 seed_offset ; float bias_corr1 ; float bias_corr2 }.  A captured training
+// step bakes every by-value argument, so what changes from step to step (the dropout seed, AdamW's bias corrections)
+// is read by the kernels from these words (seed_dev / bc_dev arguments) and rewritten here before each replay.
+__global__ void step_state_kernel(uint64_t* __restrict__ state, uint64_t seed_offset, float bc1, float bc2) {
+  state[0] = seed_offset;
+  float* f = (float*)(state + 1);
+  f[0] = bc1;
+  f[1] = bc2;
+}
+
+extern "C" int scp_step_state_set(void* state, uint64_t seed_offset, float bias_corr1, float bias_corr2, void* stream_) {
+  SCP_CHECK(state && ((uintptr_t)state % 8) == 0, SCP_ERR_ARG, "scp_step_state_set: state must be an 8-byte aligned device pointer");
+  SCP_CHECK(bias_corr1 > 0.f && bias_corr2 > 0.f, SCP_ERR_ARG, "scp_step_state_set: bias corrections must be > 0");
+  hipLaunchKernelGGL(step_state_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, (uint64_t*)state, seed_offset,
+                     bias_corr1, bias_corr2);
+  SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

@@ -37,6 +37,19 @@ enum {
   SCP_ERR_HIP = -100     // HIP runtime error, see scp_last_error()
 };
 
+// Opt a kernel in to `smem` bytes of dynamic LDS.  The attribute is per device: `done` is a bit mask over device
+// indices (one static word per kernel instantiation at the call site).
+static inline int scp_set_smem(const void* fn, size_t smem, uint64_t* done) {
+  int dev = 0;
+  SCP_HIP(hipGetDevice(&dev));
+  uint64_t bit = 1ull << (dev & 63);
+  if (!(*done & bit)) {
+    SCP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    *done |= bit;
+  }
+  return SCP_OK;
+}
+
 // ---- bf16 split: f = hi + mid + lo (each bf16), 24 significant bits in total ----------------
 template <int NS>
 __device__ __forceinline__ void bf16_split(float f, __bf16* out) {
@@ -246,6 +259,13 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
   z = z ^ (z >> 31);
   return (uint32_t)(z >> 32);
 }
+// dropout seed of a launch = by-value base + an optional device-resident per-step offset (HIP-graph replays: the graph
+// bakes the by-value arguments, the offset word is rewritten before every replay by scp_step_state_set)
+struct SeedArg {
+  uint64_t base;
+  const uint64_t* dev;
+};
+__device__ __forceinline__ uint64_t seed_of(const SeedArg& s) { return s.dev ? s.base + s.dev[0] : s.base; }
 __device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p) {
   if (p <= 0.f) return 1.f;
   float u = (float)(hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);

@@ -591,13 +591,10 @@ template <int NS, int KP, int MODE>
 static int dec_launch(const DecArgs& g, int grid, hipStream_t stream) {
   const int ncb_ = (g.B + CB - 1) / CB;
   const int ncg_ = (ncb_ + g.cpg - 1) / g.cpg;
-  static bool attr_done = false;
+  static uint64_t attr_done = 0;
   size_t smem = dec_smem<NS, KP>();
-  if (!attr_done) {
-    SCP_HIP(hipFuncSetAttribute((const void*)dec_kernel<NS, KP, DEC_NPT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem));
-    attr_done = true;
-  }
+  int rc_ = scp_set_smem((const void*)dec_kernel<NS, KP, DEC_NPT, MODE>, smem, &attr_done);
+  if (rc_) return rc_;
   hipLaunchKernelGGL((dec_kernel<NS, KP, DEC_NPT, MODE>), dim3(grid, ncg_), dim3(256), smem, stream, g);
   SCP_LAUNCH_CHECK();
   return SCP_OK;

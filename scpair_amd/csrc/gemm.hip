@@ -260,12 +260,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 template <int NS, int AK, int BK_>
 static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
-  static bool attr_done = false;
+  static uint64_t attr_done = 0;
   size_t smem = (size_t)NS * 2 * TM * LDK * sizeof(__bf16);
-  if (!attr_done) {
-    SCP_HIP(hipFuncSetAttribute((const void*)gemm_kernel<NS, AK, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
-  }
+  int rc_ = scp_set_smem((const void*)gemm_kernel<NS, AK, BK_>, smem, &attr_done);
+  if (rc_) return rc_;
   int units = g.tiles_n * g.nsplit;
   int grid = 8 * g.tiles_m * ((units + 7) / 8);
   hipLaunchKernelGGL((gemm_kernel<NS, AK, BK_>), dim3(grid), dim3(256), smem, stream, g);

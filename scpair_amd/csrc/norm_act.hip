@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const float* __restrict
                                                          int nslab, const float* __restrict__ bias,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int B, int H, float eps,
-                                                         float slope, float p_drop, uint64_t seed,
+                                                         float slope, float p_drop, SeedArg seed,
                                                          float* __restrict__ xhat, long ldx, float* __restrict__ rstd_out,
                                                          float* __restrict__ out, long ldo) {
   int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const float* __restrict
       float xh = gamma ? (v[i] - mean) * rstd : v[i];
       float z = gamma ? xh * gamma[c] + beta[c] : xh;
       float a = z > 0.f ? z : z * slope;
-      a *= keep_scale(seed, (uint64_t)row * H + c, p_drop);
+      a *= keep_scale(seed_of(seed), (uint64_t)row * H + c, p_drop);
       if (xhat) xhat[(long)row * ldx + c] = xh;
       out[(long)row * ldo + c] = a;
     }
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ rstd_in,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int B, int H, float slope,
-                                                         float p_drop, uint64_t seed, float* __restrict__ dY, long ldy,
+                                                         float p_drop, SeedArg seed, float* __restrict__ dY, long ldy,
                                                          float* __restrict__ partials /* [grid][3][H] */) {
   __shared__ float red[3][4][64];
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
       xh[i] = 0.f;
       if (c < H) {
         float x = xhat[(long)row * ldx + c];
-        float g = dOut[(long)row * ldo + c] * keep_scale(seed, (uint64_t)row * H + c, p_drop);
+        float g = dOut[(long)row * ldo + c] * keep_scale(seed_of(seed), (uint64_t)row * H + c, p_drop);
         float z = gamma ? x * gamma[c] + beta[c] : x;
         float dz = z > 0.f ? g : g * slope;
         xh[i] = x;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_row_kernel(const float* __rest
                                                              int nslab, const float* __restrict__ bias,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int B, int H, float eps,
-                                                             float slope, float p_drop, uint64_t seed,
+                                                             float slope, float p_drop, SeedArg seed,
                                                              float* __restrict__ xhat, long ldx,
                                                              float* __restrict__ rstd_out, float* __restrict__ out,
                                                              long ldo) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_row_kernel(const float* __rest
       float xh = gamma ? (v[i] - mean) * rstd : v[i];
       float z = gamma ? xh * gamma[c] + beta[c] : xh;
       float a = z > 0.f ? z : z * slope;
-      a *= keep_scale(seed, (uint64_t)row * H + c, p_drop);
+      a *= keep_scale(seed_of(seed), (uint64_t)row * H + c, p_drop);
       if (xhat) xhat[(long)row * ldx + c] = xh;
       out[(long)row * ldo + c] = a;
     }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_row_kernel(const float* __rest
                                                              const float* __restrict__ rstd_in,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int B, int H,
-                                                             float slope, float p_drop, uint64_t seed,
+                                                             float slope, float p_drop, SeedArg seed,
                                                              float* __restrict__ dY, long ldy,
                                                              float* __restrict__ partials /* [grid][3][H] */) {
   __shared__ float red[2][4];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_row_kernel(const float* __rest
       xh[i] = 0.f;
       if (c < H) {
         float x = xhat[(long)row * ldx + c];
-        float g = dOut[(long)row * ldo + c] * keep_scale(seed, (uint64_t)row * H + c, p_drop);
+        float g = dOut[(long)row * ldo + c] * keep_scale(seed_of(seed), (uint64_t)row * H + c, p_drop);
         float z = gamma ? x * gam[i] + bet[i] : x;
         float dz = z > 0.f ? g : g * slope;
         xh[i] = x;
@@ -340,8 +340,9 @@ static int ln_bwd_wave_grid(int B) {
 
 extern "C" int scp_ln_act_fwd(const float* Y, long ldy, long slab_stride, int nslab, const float* bias,
                               const float* gamma, const float* beta, int B, int H, float eps, float slope,
-                              float p_drop, uint64_t seed, float* xhat, long ldx, float* rstd, float* out, long ldo,
+                              float p_drop, uint64_t seed_, const uint64_t* seed_dev, float* xhat, long ldx, float* rstd, float* out, long ldo,
                               void* stream_) {
+  const SeedArg seed = {seed_, seed_dev};
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(B > 0 && H > 0, SCP_ERR_ARG, "scp_ln_act_fwd: B,H must be positive");
   SCP_CHECK(Y && out, SCP_ERR_ARG, "scp_ln_act_fwd: null pointer");
@@ -367,8 +368,9 @@ extern "C" int scp_ln_act_fwd(const float* Y, long ldy, long slab_stride, int ns
 
 extern "C" int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, long ldx, const float* rstd,
                               const float* gamma, const float* beta, int B, int H, float slope, float p_drop,
-                              uint64_t seed, float* dY, long ldy, float* dgamma, float* dbeta, float* dbias,
+                              uint64_t seed_, const uint64_t* seed_dev, float* dY, long ldy, float* dgamma, float* dbeta, float* dbias,
                               float* partials_ws, void* stream_) {
+  const SeedArg seed = {seed_, seed_dev};
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(B > 0 && H > 0, SCP_ERR_ARG, "scp_ln_act_bwd: B,H must be positive");
   SCP_CHECK(dOut && xhat && dY && partials_ws, SCP_ERR_ARG, "scp_ln_act_bwd: null pointer");
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ run_mean, float* __restrict__ run_var,
                                                      int training, float momentum, float eps, float p_drop,
-                                                     uint64_t seed, float* __restrict__ save_mean,
+                                                     SeedArg seed, float* __restrict__ save_mean,
                                                      float* __restrict__ save_rstd, float* __restrict__ y, long ldy) {
   __shared__ float red[8][32];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x
   const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
   for (int r = ry; r < B; r += 8) {
     float v = (x[(long)r * ldx + c] - mean) * rstd * g + bt;
-    y[(long)r * ldy + c] = v * keep_scale(seed, (uint64_t)r * H + c, p_drop);
+    y[(long)r * ldy + c] = v * keep_scale(seed_of(seed), (uint64_t)r * H + c, p_drop);
   }
 }
 
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
                                                      long ldx, int B, int H, const float* __restrict__ gamma,
                                                      const float* __restrict__ save_mean,
                                                      const float* __restrict__ save_rstd, int training, float p_drop,
-                                                     uint64_t seed, float* __restrict__ dx, long lddx,
+                                                     SeedArg seed, float* __restrict__ dx, long lddx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[8][32];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
   float s1 = 0.f, s2 = 0.f;
   if (ok)
     for (int r = ry; r < B; r += 8) {
-      float g = dy[(long)r * lddy + c] * keep_scale(seed, (uint64_t)r * H + c, p_drop);
+      float g = dy[(long)r * lddy + c] * keep_scale(seed_of(seed), (uint64_t)r * H + c, p_drop);
       float xh = (x[(long)r * ldx + c] - mean) * rstd;
       s1 += g;
       s2 += g * xh;
@@ -571,15 +573,16 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
   const float g_ = (gamma ? gamma[c] : 1.f) * rstd;
   const float m1 = training ? s1 / (float)B : 0.f, m2 = training ? s2 / (float)B : 0.f;
   for (int r = ry; r < B; r += 8) {
-    float g = dy[(long)r * lddy + c] * keep_scale(seed, (uint64_t)r * H + c, p_drop);
+    float g = dy[(long)r * lddy + c] * keep_scale(seed_of(seed), (uint64_t)r * H + c, p_drop);
     float xh = (x[(long)r * ldx + c] - mean) * rstd;
     dx[(long)r * lddx + c] = g_ * (g - m1 - xh * m2);
   }
 }
 
 extern "C" int scp_bn_fwd(const float* x, long ldx, int B, int H, const float* gamma, const float* beta, float* run_mean,
-                          float* run_var, int training, float momentum, float eps, float p_drop, uint64_t seed,
+                          float* run_var, int training, float momentum, float eps, float p_drop, uint64_t seed_, const uint64_t* seed_dev,
                           float* save_mean, float* save_rstd, float* y, long ldy, void* stream_) {
+  const SeedArg seed = {seed_, seed_dev};
   SCP_CHECK(B > 0 && H > 0 && x && y && save_mean && save_rstd, SCP_ERR_ARG, "scp_bn_fwd: bad argument");
   SCP_CHECK(training || (run_mean && run_var), SCP_ERR_ARG, "scp_bn_fwd: eval mode needs running statistics");
   SCP_CHECK((gamma == nullptr) == (beta == nullptr), SCP_ERR_ARG, "scp_bn_fwd: gamma and beta go together");
@@ -591,8 +594,9 @@ extern "C" int scp_bn_fwd(const float* x, long ldx, int B, int H, const float* g
 }
 
 extern "C" int scp_bn_bwd(const float* dy, long lddy, const float* x, long ldx, int B, int H, const float* gamma,
-                          const float* save_mean, const float* save_rstd, int training, float p_drop, uint64_t seed,
+                          const float* save_mean, const float* save_rstd, int training, float p_drop, uint64_t seed_, const uint64_t* seed_dev,
                           float* dx, long lddx, float* dgamma, float* dbeta, void* stream_) {
+  const SeedArg seed = {seed_, seed_dev};
   SCP_CHECK(B > 0 && H > 0 && dy && x && dx && save_mean && save_rstd, SCP_ERR_ARG, "scp_bn_bwd: bad argument");
   hipLaunchKernelGGL(bn_bwd_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream_, dy, lddy, x, ldx, B, H, gamma,
                      save_mean, save_rstd, training, p_drop, seed, dx, lddx, dgamma, dbeta);

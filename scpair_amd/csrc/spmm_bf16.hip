@@ -28,6 +28,7 @@ struct SpArgs {
   // wgrad with the AdamW update applied in the epilogue (C = the fp32 master weights, updated in place)
   float* adam_m; float* adam_v; __bf16* adam_sh; long adam_ldsh;
   float lr, wd, b1, b2, eps, bc1, bc2, gscale;
+  const float* bc_dev;       // optional device words {bias_corr1, bias_corr2} (HIP-graph replays), else bc1 / bc2
 };
 
 __device__ __forceinline__ uint4 ld16(const __bf16* p, bool ok) {
@@ -486,7 +487,8 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
           gt[(wm * 64 + i2 * 32 + acc_row(e, lane)) * GLD + wn * 64 + jj * 32 + r] = acc[i2][jj][e];
     __syncthreads();
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const AdamHyper hy = adam_hyper(g.lr, g.wd, g.b1, g.b2, g.eps, g.bc1, g.bc2, g.gscale);
+    const float bc1 = g.bc_dev ? g.bc_dev[0] : g.bc1, bc2 = g.bc_dev ? g.bc_dev[1] : g.bc2;
+    const AdamHyper hy = adam_hyper(g.lr, g.wd, g.b1, g.b2, g.eps, bc1, bc2, g.gscale);
     const int c4 = (tid & 63) * 4, rw = tid >> 6;   // one wave per 1 KB row segment, 8 rows per pass
     const int n = n0 + c4;
     const bool col_ok = n + 4 <= g.F;               // F % 4 == 0 (host-checked): a float4 is all in or all out
@@ -578,13 +580,7 @@ extern "C" int scp_transpose_bf16(const float* src, int rows, int cols, long ld_
   return SCP_OK;
 }
 
-static int set_smem(const void* fn, size_t smem, bool* done) {
-  if (!*done) {
-    SCP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    *done = true;
-  }
-  return SCP_OK;
-}
+static int set_smem(const void* fn, size_t smem, uint64_t* done) { return scp_set_smem(fn, smem, done); }
 
 // smallest split-K factor scp_spmm_fwd_bf16 accepts for F features (its per-slab offset table holds PCH K-steps)
 extern "C" int scp_spmm_fwd_bf16_min_split(int F) {
@@ -598,7 +594,7 @@ extern "C" int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr,
   SCP_CHECK(t_ptr && t_key && Wbf && Y, SCP_ERR_ARG, "scp_spmm_fwd_bf16: null pointer");
   SCP_CHECK(ldw % 8 == 0 && ldw >= F && ((uintptr_t)Wbf % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_fwd_bf16: shadow weights need a 16-byte aligned base and ld %% 8 == 0");
-  static bool done_v = false, done_n = false;
+  static uint64_t done_v = 0, done_n = 0;
   size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 4 * (PCH + 1) * sizeof(int);
   int rc = t_val ? set_smem((const void*)spmm_fwd_bf16_kernel<true>, smem, &done_v)
                  : set_smem((const void*)spmm_fwd_bf16_kernel<false>, smem, &done_n);
@@ -633,7 +629,7 @@ extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, 
             "scp_spmm_dw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
   SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16: more than %d cells per call unsupported",
             64 * (PCH + 1));
-  static bool done_v = false, done_n = false;
+  static uint64_t done_v = 0, done_n = 0;
   size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
   int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true, false>, smem, &done_v)
                  : set_smem((const void*)spmm_dw_bf16_kernel<false, false>, smem, &done_n);
@@ -655,7 +651,7 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
                                       const float* t_val, const void* dYT, long ldt, float* W, long ldw, float* exp_avg,
                                       float* exp_avg_sq, void* W_bf16, long ld_bf16, float lr, float weight_decay,
                                       float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
-                                      float grad_scale, void* stream_) {
+                                      float grad_scale, const float* bc_dev, void* stream_) {
   SCP_CHECK(ncells > 0 && N > 0 && F > 0, SCP_ERR_ARG, "scp_spmm_dw_adamw_bf16: sizes must be positive");
   SCP_CHECK(t_ptr && t_key && dYT && W && exp_avg && exp_avg_sq && W_bf16, SCP_ERR_ARG,
             "scp_spmm_dw_adamw_bf16: null pointer");
@@ -666,8 +662,9 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
   SCP_CHECK(F % 4 == 0 && ldw % 4 == 0 && ldw >= F && ld_bf16 % 4 == 0 && ld_bf16 >= F &&
                 (((uintptr_t)W | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) == 0 && ((uintptr_t)W_bf16 % 8) == 0,
             SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: needs F %% 4 == 0, leading dimensions %% 4 == 0 and 16-byte aligned W / moments");
-  SCP_CHECK(bias_corr1 > 0.f && bias_corr2 > 0.f, SCP_ERR_ARG, "scp_spmm_dw_adamw_bf16: bias corrections must be > 0");
-  static bool done_v = false, done_n = false;
+  SCP_CHECK(bc_dev || (bias_corr1 > 0.f && bias_corr2 > 0.f), SCP_ERR_ARG,
+            "scp_spmm_dw_adamw_bf16: bias corrections must be > 0");
+  static uint64_t done_v = 0, done_n = 0;
   size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
   static_assert((size_t)128 * 260 * sizeof(float) <= (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16),
                 "gradient tile must fit in the operand buffers");
@@ -680,7 +677,7 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
   g.tiles_m = (N + 127) / 128; g.tiles_n = (F + 255) / 256; g.nsplit = 1;
   g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_sh = (__bf16*)W_bf16; g.adam_ldsh = ld_bf16;
   g.lr = lr; g.wd = weight_decay; g.b1 = beta1; g.b2 = beta2; g.eps = eps; g.bc1 = bias_corr1; g.bc2 = bias_corr2;
-  g.gscale = grad_scale;
+  g.gscale = grad_scale; g.bc_dev = bc_dev;
   int grid = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
   if (t_val)
     hipLaunchKernelGGL((spmm_dw_bf16_kernel<true, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
@@ -698,7 +695,7 @@ extern "C" int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_p
             "scp_spmm_dw_bf16_g16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
   SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16_g16: more than %d cells per call unsupported",
             64 * (PCH + 1));
-  static bool done_v = false, done_n = false;
+  static uint64_t done_v = 0, done_n = 0;
   size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
   int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true, false, true>, smem, &done_v)
                  : set_smem((const void*)spmm_dw_bf16_kernel<false, false, true>, smem, &done_n);

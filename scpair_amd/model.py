@@ -298,6 +298,52 @@ def _index_loader(n, batch_size, drop_last=False):
     return torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=0, drop_last=drop_last)
 
 
+class _GraphStepper:
+    """Full-size minibatch steps of one predictor (model.py:729-763) through a HIP graph: the first steps run eagerly
+    (optimiser state, weight shadows and kernel attributes come into being), the next one is recorded, the rest are
+    replays.  Ragged batches (the last one of an epoch, drop_last=False) stay eager."""
+    WARM = 2
+
+    def __init__(self, owner, xtr, ytr, ctr, use_lib, encoder, decoder, optimizer, dist):
+        self.o, self.xtr, self.ytr, self.ctr, self.use_lib = owner, xtr, ytr, ctr, use_lib
+        self.enc, self.dec, self.opt, self.dist = encoder, decoder, optimizer, dist
+        self.B = int(owner.batch_size)
+        self.seen = 0
+        self.cs = None
+        self.ok = all(m.momentum is not None for mod in (encoder, decoder) for m in mod.modules()
+                      if isinstance(m, nn.BatchNorm1d))       # cumulative-average BN keeps a host-side counter
+
+    def wants(self, rows):
+        if not self.ok or len(rows) != self.B:
+            return False
+        if self.cs is not None:
+            return True
+        self.seen += 1
+        return self.seen > self.WARM
+
+    def _fn(self, rows_dev):
+        tx = BatchTiles(self.xtr, rows_dev, want_lib=False, capacity=self.cap_x)
+        ty = BatchTiles(self.ytr, rows_dev, want_lib=self.use_lib, capacity=self.cap_y)
+        c = None if self.ctr is None else self.ctr[rows_dev]
+        lib = ty.lib.reshape(-1, 1) if self.use_lib else None
+        return train_net(tx, ty, lib, self.enc, self.dec, self.opt, likelihood_type=self.dist, add_cov=c is not None,
+                         input_batch=c, output_batch=c)
+
+    def step(self, rows, rows_dev):
+        if rows.min() < 0 or rows.max() >= self.xtr.n_rows:
+            raise IndexError("minibatch row id out of range")
+        if self.cs is None:
+            from .graph import CapturedStep
+            self.cap_x, self.cap_y = self.xtr.max_batch_nnz(self.B), self.ytr.max_batch_nnz(self.B)
+            self.cs = CapturedStep(self._fn, [self.opt], self.B, self.o.device).capture(rows_dev)
+        return self.cs(rows_dev).clone()
+
+    def release(self):
+        if self.cs is not None:
+            self.cs.release()
+            self.cs = None
+
+
 class scPair_object():
     """model.py:341-1036.  Same constructor surface; `device` must be a GPU."""
 
@@ -347,7 +393,7 @@ class scPair_object():
                  memory_efficient_loading=True,
                  val_chunk=4096,
                  verbose=True,
-                 grad_sync=None, fuse_optimizer=True, input_transform=None):
+                 grad_sync=None, fuse_optimizer=True, input_transform=None, capture_step=False):
         self.scobj = scobj
         self.modalities = modalities
         self.modality_names = list(modalities.keys())
@@ -398,6 +444,9 @@ class scPair_object():
         self.verbose = verbose
         self.grad_sync = grad_sync          # data-parallel hook (scpair_amd.distributed.GradSync) or None
         self.fuse_optimizer = fuse_optimizer  # AdamW step of the first-layer weights inside their dW kernel (1 process)
+        # opt-in, single process: full-size minibatch steps are recorded once per direction as a HIP graph and
+        # replayed (scpair_amd.graph.CapturedStep; same kernels in the same order, so results do not change)
+        self.capture_step = capture_step
         # Opt-in input pre-transform per modality, e.g. {'Gene Expression': 'log1p_norm'} or {'Gene Expression':
         # ('log1p_norm', 1e4)}: applied to encoder inputs only, on the fly in the minibatch tile list.  The reference
         # has no normalisation anywhere (model.py:492-510 feeds raw counts), so the default None keeps parity.
@@ -751,6 +800,8 @@ class scPair_object():
             replay = None if batch_replay is None else list(batch_replay[di])
             per_epoch = None if replay is None else int(np.ceil(xtr.n_rows / self.batch_size))
             encoder_ckpt = decoder_ckpt = None
+            stepper = _GraphStepper(self, xtr, ytr, ctr, use_lib, encoder, decoder, optimizer, dist) \
+                if (self.capture_step and self.grad_sync is None and scheduler is None and dist != 'gau') else None
             for epoch in range(self.max_epochs):
                 training_mode(encoder, decoder)
                 if replay is not None:
@@ -765,6 +816,9 @@ class scPair_object():
                         rows = self.grad_sync.shard(rows)
                     rows = np.asarray(rows, dtype=np.int64)
                     rows_dev = torch.from_numpy(rows).to(self.device)          # one upload, shared by both modalities
+                    if stepper is not None and stepper.wants(rows):
+                        step_losses.append(stepper.step(rows, rows_dev))
+                        continue
                     tx = BatchTiles(xtr, rows_dev, want_lib=False, rows_host=rows)
                     c = None if ctr is None else ctr[rows_dev]
                     if dist == 'gau':
@@ -789,6 +843,8 @@ class scPair_object():
                     self._say("Early Stopped!")
                     break
             hist["train_loss"] = [float(v) for v in torch.stack(hist["train_loss"]).cpu()] if hist["train_loss"] else []
+            if stepper is not None:
+                stepper.release()
             key = input_modality + ' to ' + output_modality
             self.history[key] = hist
             encoder_dict[key] = copy.deepcopy(encoder_ckpt.eval())

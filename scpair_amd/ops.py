@@ -44,6 +44,36 @@ def next_seed() -> int:
     return ((torch.initial_seed() & 0xFFFFFFFF) << 24) + _cfg["seed_ctr"]
 
 
+class StepState:
+    """16 bytes of device memory {uint64 seed offset; float bias_corr1; float bias_corr2} behind a training step
+    captured in a HIP graph (scpair_amd.graph.CapturedStep): the graph bakes every by-value kernel argument, so the
+    dropout kernels add `seed_ptr[0]` to their seed and the AdamW kernels read their bias corrections from `bc_ptr`;
+    `set()` rewrites the words before each replay (scp_step_state_set, by-value arguments of a tiny launch)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(2, dtype=torch.int64, device=device)
+        self.seed_ptr = self.buf.data_ptr()
+        self.bc_ptr = self.buf.data_ptr() + 8
+
+    def set(self, seed_offset: int, bc1: float, bc2: float):
+        _lib.check(_lib.lib().scp_step_state_set(self.buf.data_ptr(), int(seed_offset) & 0xFFFFFFFFFFFFFFFF, float(bc1),
+                                                 float(bc2), _lib.stream()), "scp_step_state_set")
+
+
+_cfg["step_state"] = None
+
+
+def set_step_state(state):
+    """The StepState the dropout kernels launched from now on read their seed offset from (None: by-value seeds only).
+    Set by CapturedStep around the capture of a training step."""
+    _cfg["step_state"] = state
+
+
+def _seed_dev():
+    st = _cfg["step_state"]
+    return None if st is None else st.seed_ptr
+
+
 # ---- bf16 shadow copies of first-layer weights (precision 'bf16') ------------------------------------------
 import weakref
 
@@ -275,13 +305,15 @@ class FcnnLayerFn(torch.autograd.Function):
         xhat = torch.empty((Bn, H), dtype=torch.float32, device=dev)
         rstd = torch.empty((Bn,), dtype=torch.float32, device=dev)
         g_, b_ = _f32c(gamma), _f32c(beta)
+        seed_dev = _seed_dev() if p_drop > 0 else None
         _lib.check(L.scp_ln_act_fwd(slabs.data_ptr(), H, Bn * H, nslab, _lib.ptr(_f32c(b)), _lib.ptr(g_), _lib.ptr(b_),
-                                    Bn, H, eps, slope, p_drop, seed, xhat.data_ptr(), H, rstd.data_ptr(),
+                                    Bn, H, eps, slope, p_drop, seed, seed_dev, xhat.data_ptr(), H, rstd.data_ptr(),
                                     out.data_ptr(), H, _lib.stream()), "scp_ln_act_fwd")
         ctx.sparse = sparse
         ctx.tiles = x if sparse else None
         ctx.save_for_backward(xs, covc, Wc, g_, b_, xhat, rstd)
         ctx.cfg = (slope, p_drop, seed, Bn, H, F, C_, ns, b is not None)
+        ctx.seed_dev = seed_dev
         ctx.use_bf = use_bf
         ctx.fused = fused if (use_bf and C_ == 0 and Ftot % 4 == 0) else None
         ctx.sink = sink if (use_bf and C_ == 0 and ctx.fused is None) else None
@@ -301,7 +333,7 @@ class FcnnLayerFn(torch.autograd.Function):
         dbias = torch.empty(H, dtype=torch.float32, device=dev) if has_bias else None
         ws = torch.empty(L.scp_ln_act_bwd_grid(Bn) * 3 * H, dtype=torch.float32, device=dev)
         _lib.check(L.scp_ln_act_bwd(dout.data_ptr(), H, xhat.data_ptr(), H, rstd.data_ptr(), _lib.ptr(gamma),
-                                    _lib.ptr(beta), Bn, H, slope, p_drop, seed, dY.data_ptr(), H, _lib.ptr(dgamma),
+                                    _lib.ptr(beta), Bn, H, slope, p_drop, seed, ctx.seed_dev, dY.data_ptr(), H, _lib.ptr(dgamma),
                                     _lib.ptr(dbeta), _lib.ptr(dbias), ws.data_ptr(), _lib.stream()), "scp_ln_act_bwd")
         dx = dW = None
         if ctx.needs_input_grad[2]:
@@ -380,9 +412,11 @@ class BatchNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = _empty((H,), x)
         rstd = _empty((H,), x)
+        seed_dev = _seed_dev() if p_drop > 0 else None
         _lib.check(L.scp_bn_fwd(x.data_ptr(), H, B, H, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(run_mean),
                                 _lib.ptr(run_var), int(training), float(momentum), float(eps), float(p_drop), int(seed),
-                                mean.data_ptr(), rstd.data_ptr(), y.data_ptr(), H, _lib.stream()), "scp_bn_fwd")
+                                seed_dev, mean.data_ptr(), rstd.data_ptr(), y.data_ptr(), H, _lib.stream()), "scp_bn_fwd")
+        ctx.seed_dev = seed_dev
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.cfg = (bool(training), float(p_drop), int(seed))
         return y
@@ -398,7 +432,7 @@ class BatchNormFn(torch.autograd.Function):
         dg = _empty((H,), x) if gamma is not None else None
         db = _empty((H,), x) if gamma is not None else None
         _lib.check(L.scp_bn_bwd(dy.data_ptr(), H, x.data_ptr(), H, B, H, _lib.ptr(gamma), mean.data_ptr(),
-                                rstd.data_ptr(), int(training), p_drop, seed, dx.data_ptr(), H, _lib.ptr(dg),
+                                rstd.data_ptr(), int(training), p_drop, seed, ctx.seed_dev, dx.data_ptr(), H, _lib.ptr(dg),
                                 _lib.ptr(db), _lib.stream()), "scp_bn_bwd")
         return dx, dg, db, None, None, None, None, None, None, None
 
@@ -726,8 +760,13 @@ class FusedFirstLayer:
         b1, b2 = self.group["betas"]
         sh = shadow_of(p)
         self.pending = True
+        dyn = opt.step_state
+        if dyn is not None:               # captured step: bias corrections come from the device words
+            opt._dyn_note(p, (b1, b2))
+            return st["exp_avg"], st["exp_avg_sq"], sh, (self.group["lr"], self.group["weight_decay"], b1, b2,
+                                                         self.group["eps"], 1.0, 1.0, 1.0, dyn.bc_ptr)
         return st["exp_avg"], st["exp_avg_sq"], sh, (self.group["lr"], self.group["weight_decay"], b1, b2,
-                                                     self.group["eps"], 1 - b1 ** t, 1 - b2 ** t, 1.0)
+                                                     self.group["eps"], 1 - b1 ** t, 1 - b2 ** t, 1.0, None)
 
 
 _fused = {}            # id(parameter) -> FusedFirstLayer
@@ -790,6 +829,44 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.step_state = None          # StepState while a step of this optimiser is being captured / replayed
+        self._dyn_params = {}           # id(p) -> p: parameters the captured step updates
+        self._dyn_betas = None
+
+    # -- a step captured in a HIP graph: 'step' counters advance on the host, bias corrections live on the device ---
+    def _dyn_note(self, p, betas):
+        if self._dyn_betas is None:
+            self._dyn_betas = tuple(betas)
+        elif self._dyn_betas != tuple(betas):
+            raise RuntimeError("a captured step needs the same betas in every parameter group")
+        self._dyn_params[id(p)] = p
+
+    def begin_capture(self, state):
+        self.step_state, self._dyn_params, self._dyn_betas = state, {}, None
+
+    def end_capture(self):
+        """Capture done: eager step() calls compute their bias corrections on the host again; the captured step keeps
+        reading the device words, and dyn_advance() keeps the host counters of its parameters in step."""
+        self.step_state = None
+        steps = {self.state[p]["step"] for p in self._dyn_params.values()}
+        if len(steps) > 1:
+            raise RuntimeError("a captured step needs every parameter it updates at the same step count")
+
+    def release_capture(self):
+        self.step_state, self._dyn_params, self._dyn_betas = None, {}, None
+
+    def dyn_advance(self):
+        """Before a replay: advance the host-side step counters of the parameters the captured step updates and
+        return the bias corrections (1 - beta1^t, 1 - beta2^t) of that step (computed as step() does)."""
+        t = None
+        for p in self._dyn_params.values():
+            st = self.state[p]
+            st["step"] += 1
+            t = st["step"]
+        if t is None:
+            return 1.0, 1.0
+        b1, b2 = self._dyn_betas
+        return 1 - b1 ** t, 1 - b2 ** t
 
     # -- AdamW step of the sparse first-layer weights inside their weight-gradient kernel ----------------------
     def fuse_first_layer(self, *params):
@@ -835,7 +912,8 @@ class FusedAdamW(torch.optim.Optimizer):
                         raise RuntimeError("FusedAdamW: grad_scale is not available for weights updated during backward()")
                     if p.grad is not None:
                         raise RuntimeError("FusedAdamW: a weight updated during backward() also received a gradient")
-                    self.state[p]["step"] += 1
+                    if self.step_state is None:
+                        self.state[p]["step"] += 1
                     fz.pending = False
                     continue
                 g16 = 0
@@ -854,13 +932,19 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                t = st["step"]
+                dyn = self.step_state
+                if dyn is None:
+                    st["step"] += 1
+                    t = st["step"]
+                    bc1, bc2, bc_dev = 1 - b1 ** t, 1 - b2 ** t, None
+                else:                         # captured step: counters advance in dyn_advance(), once per replay
+                    self._dyn_note(p, (b1, b2))
+                    bc1, bc2, bc_dev = 1.0, 1.0, dyn.bc_ptr
                 sh = shadow_of(p, create=False) if p.ndim == 2 else None
                 d = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                    p.numel(), group["lr"], group["weight_decay"], 1 - b1 ** t, 1 - b2 ** t, grad_scale,
+                                    p.numel(), group["lr"], group["weight_decay"], bc1, bc2, grad_scale,
                                     None if sh is None else sh.data_ptr(), p.shape[-1],
-                                    0 if sh is None else sh.shape[1], g16)
+                                    0 if sh is None else sh.shape[1], g16, bc_dev)
                 by_hyper.setdefault((b1, b2, group["eps"]), []).append(d)
                 keep.append(g)
         for (b1, b2, eps), descs in by_hyper.items():

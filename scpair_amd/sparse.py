@@ -103,6 +103,14 @@ class DeviceCSR:
     def n_cols(self):
         return self.shape[1]
 
+    def max_batch_nnz(self, batch: int) -> int:
+        """Upper bound of the entries of any minibatch of `batch` distinct rows (the sum of the `batch` longest rows):
+        the fixed tile-list capacity of a training step captured in a HIP graph."""
+        lens = np.diff(self.indptr_host)
+        if batch >= lens.shape[0]:
+            return int(lens.sum())
+        return int(np.partition(lens, lens.shape[0] - batch)[lens.shape[0] - batch:].sum())
+
     def nnz_of(self, rows_host: np.ndarray) -> int:
         ip = self.indptr_host
         return int((ip[rows_host + 1] - ip[rows_host]).sum())
@@ -129,24 +137,34 @@ class BatchTiles:
     nnan: int32 [1]           number of NaN values (missing labels)
     """
 
-    def __init__(self, csr: DeviceCSR, rows, want_lib=True, rows_host=None):
+    def __init__(self, csr: DeviceCSR, rows, want_lib=True, rows_host=None, capacity=None):
+        """`capacity`: build without looking at the row ids on the host (a step captured in a HIP graph: `rows` is a
+        device tensor whose CONTENTS change between replays): the entry buffers get `capacity` slots
+        (>= csr.max_batch_nnz(len(rows))) and the caller guarantees distinct, in-range row ids."""
         L = _lib.lib()
         dev = csr.device
-        if isinstance(rows, torch.Tensor):
-            rows_dev = rows.to(device=dev, dtype=torch.int64).contiguous()
-            if rows_host is None:
-                rows_host = rows.detach().cpu().numpy()
+        if capacity is not None:
+            if not (isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dtype == torch.int64 and rows.is_contiguous()):
+                raise ValueError("fixed-capacity tile lists need a contiguous int64 device tensor of row ids")
+            rows_dev = rows
+            self.B = int(rows.shape[0])
+            self.nnz = int(capacity)
         else:
-            rows_host = np.asarray(rows, dtype=np.int64)
-            rows_dev = torch.from_numpy(rows_host).to(dev)
-        rows_host = np.asarray(rows_host, dtype=np.int64)
-        self.B = int(rows_host.shape[0])
+            if isinstance(rows, torch.Tensor):
+                rows_dev = rows.to(device=dev, dtype=torch.int64).contiguous()
+                if rows_host is None:
+                    rows_host = rows.detach().cpu().numpy()
+            else:
+                rows_host = np.asarray(rows, dtype=np.int64)
+                rows_dev = torch.from_numpy(rows_host).to(dev)
+            rows_host = np.asarray(rows_host, dtype=np.int64)
+            self.B = int(rows_host.shape[0])
+            if self.B and (rows_host.min() < 0 or rows_host.max() >= csr.n_rows):
+                raise IndexError("minibatch row id out of range")
+            self.nnz = csr.nnz_of(rows_host) if self.B else 0
         self.F = csr.n_cols
         if self.B == 0:
             raise ValueError("empty minibatch")
-        if rows_host.min() < 0 or rows_host.max() >= csr.n_rows:
-            raise IndexError("minibatch row id out of range")
-        self.nnz = csr.nnz_of(rows_host)
         self.rows = rows_dev
         self.ptr = torch.empty(L.scp_tiles_ptr_len(self.B, self.F), dtype=torch.int32, device=dev)
         self.key = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)

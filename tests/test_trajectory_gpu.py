@@ -35,16 +35,26 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b) / np.abs(b)))
 
 
-def _run(name, precision):
+def _run(name, precision, **kw):
     d = U.load(name)
     c = U.cfg(d, "cfg")
     tr, va, te = _dicts(c, d)
     obj = S.scPair_object(None, cov=(["labels"] if c["with_cov"] else None), modalities=c["modalities"], SEED=0,
                           hidden_layer=c["hidden"], dropout_rate=0.0, batchnorm=c["batchnorm"], layernorm=True,
                           batch_size=c["batch"], max_epochs=c["epochs"], device=DEV, save_model=False,
-                          zero_inflated=c["zero_inflated"], use_mixed_precision=(precision == "bf16"), verbose=False)
+                          zero_inflated=c["zero_inflated"], use_mixed_precision=(precision == "bf16"), verbose=False, **kw)
     obj.train_predicting_networks(tr, va, te)
     return d, c, obj
+
+
+def test_trajectory_with_captured_steps_is_bitwise_the_eager_one():
+    """scPair_object(capture_step=True): full-size minibatch steps replayed from a HIP graph, the ragged last batch of
+    each epoch eager -- the same training and validation losses, bit for bit, as the all-eager run."""
+    _, c, eager = _run("traj_nb_ber_bn", "fp32")
+    _, _, graph = _run("traj_nb_ber_bn", "fp32", capture_step=True)
+    for k in eager.history:
+        assert eager.history[k]["train_loss"] == graph.history[k]["train_loss"], k
+        assert eager.history[k]["val_loss"] == graph.history[k]["val_loss"], k
 
 
 @pytest.mark.parametrize("name", ["traj_nb_ber", "traj_zinb_ber", "traj_nb_ber_cov", "traj_nb_ber_bn"])
