@@ -169,11 +169,14 @@ int scp_reparam_kl_fwd(const float* mu, const float* sraw, const float* eps, lon
 int scp_reparam_kl_bwd(const float* mu, const float* sraw, const float* eps, const float* sigma, const float* dz,
                        const float* dmu_in, const float* gkl, long n, float* dmu, float* dsraw, void* stream);
 
-/* ---- decoder heads for predict() (model.py:558-591) ---- */
+/* ---- decoder heads for predict() (model.py:558-591): Output_Module_Ber.forward's sigmoid * sample factor * feature
+ *      factor (model.py:173-189) and Output_Module_Raw.forward's relu -> [feature factor] -> row softmax, exp dispersion
+ *      (model.py:238-252) on the logits z.  out_bf16 != 0: `out` / `scale` are bf16 [rows][ld] (halves the bytes that
+ *      predict()'s device-to-host copy moves; the reference returns fp32) ---- */
 int scp_ber_prob(const float* z, long ldz, int rows, int cols, const float* lrow, int lrow_n, const float* fs,
-                 float* out, long ldo, void* stream);
+                 void* out, long ldo, int out_bf16, void* stream);
 int scp_relu_softmax_rows(const float* z, long ldz, int rows, int cols, const float* fs, int apply_relu,
-                          float* scale, long lds, float* theta /* nullable */, long ldt, void* stream);
+                          void* scale, long lds, float* theta /* nullable, fp32 */, long ldt, int out_bf16, void* stream);
 
 /* ---- (ZI)NB decoder heads on materialised pre-activations (loss.py:46-51; scVI_distribution.py:29-105), no feature
  *      factor.  z [B][G] = output of the mean Linear, pi [B][G] zero-inflation logits or null (plain NB), y dense

@@ -10,6 +10,7 @@ from .utils import (FCNN, HipFCNN, HipLinear, add_weight_decay, eval_net, eval_V
 from .model import (Input_Module, LazyGPUDataset, Module_Module, Output_Module_Ber, Output_Module_Gau,  # noqa: F401
                     Output_Module_Raw, clear_gpu_memory, move_to_device_safe, scPair_object)
 from .pairedVAE import VAE_DECODER, VAE_ENCODER  # noqa: F401
+from .vae_trainer import scVAE_object  # noqa: F401
 from .sparse import BatchTiles, DeviceCSR  # noqa: F401
 from .ops import FusedAdamW, get_precision, set_precision  # noqa: F401
 from .evaluator import FOSCTTM, FOSFTTM  # noqa: F401

@@ -72,8 +72,8 @@ _SIGS = {
     "scp_nbll_bwd": (I, [P, P, P, I, I, P, P, L, P, P, P, P]),
     "scp_reparam_kl_fwd": (I, [P, P, P, L, P, P, P, P, P]),
     "scp_reparam_kl_bwd": (I, [P, P, P, P, P, P, P, L, P, P, P]),
-    "scp_ber_prob": (I, [P, L, I, I, P, I, P, P, L, P]),
-    "scp_relu_softmax_rows": (I, [P, L, I, I, P, I, P, L, P, L, P]),
+    "scp_ber_prob": (I, [P, L, I, I, P, I, P, P, L, I, P]),
+    "scp_relu_softmax_rows": (I, [P, L, I, I, P, I, P, L, P, L, I, P]),
     "scp_raw_rows_fwd": (I, [P, L, P, L, P, L, P, L, P, I, I, I, P, P, P, P, P]),
     "scp_raw_rows_bwd": (I, [P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, P, L, P, L, P, L, P, P]),
     "scp_fos_counts": (I, [P, L, P, L, I, I, P, P, P, P, P]),

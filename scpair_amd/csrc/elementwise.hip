@@ -162,7 +162,8 @@ extern "C" int scp_reparam_kl_bwd(const float* mu, const float* sraw, const floa
 // Bernoulli: out = sigmoid(z) [* sigmoid(l_row)] [* sigmoid(fs_col)]   (model.py:173-189), in place allowed
 __global__ __launch_bounds__(256) void ber_prob_kernel(const float* __restrict__ z, long ldz, int rows, int cols,
                                                        const float* __restrict__ lrow, int lrow_n,
-                                                       const float* __restrict__ fs, float* __restrict__ out, long ldo) {
+                                                       const float* __restrict__ fs, void* __restrict__ out, long ldo,
+                                                       int out_bf16) {
   long n = (long)rows * cols;
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -171,15 +172,17 @@ __global__ __launch_bounds__(256) void ber_prob_kernel(const float* __restrict__
   float p = sigmoidf_(z[r * ldz + c]);
   if (lrow) p *= sigmoidf_(lrow[lrow_n == 1 ? 0 : r]);
   if (fs) p *= sigmoidf_(fs[c]);
-  out[r * ldo + c] = p;
+  if (out_bf16) ((__bf16*)out)[r * ldo + c] = (__bf16)p;
+  else ((float*)out)[r * ldo + c] = p;
 }
 
 extern "C" int scp_ber_prob(const float* z, long ldz, int rows, int cols, const float* lrow, int lrow_n, const float* fs,
-                            float* out, long ldo, void* stream_) {
+                            void* out, long ldo, int out_bf16, void* stream_) {
   SCP_CHECK(z && out && rows > 0 && cols > 0, SCP_ERR_ARG, "scp_ber_prob: bad argument");
+  SCP_CHECK(!(out_bf16 && (const void*)z == out), SCP_ERR_ARG, "scp_ber_prob: bf16 output cannot be written in place");
   long n = (long)rows * cols;
   hipLaunchKernelGGL(ber_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, z, ldz, rows,
-                     cols, lrow, lrow_n, fs, out, ldo);
+                     cols, lrow, lrow_n, fs, out, ldo, out_bf16);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
@@ -187,8 +190,8 @@ extern "C" int scp_ber_prob(const float* z, long ldz, int rows, int cols, const 
 // Raw: a = relu(z) ; scale = softmax_row(a [* sigmoid(fs)]) ; optional theta = exp(a) ; one block per row
 __global__ __launch_bounds__(256) void relu_softmax_kernel(const float* __restrict__ z, long ldz, int cols,
                                                            const float* __restrict__ fs, int apply_relu,
-                                                           float* __restrict__ scale, long lds_,
-                                                           float* __restrict__ theta, long ldt) {
+                                                           void* __restrict__ scale, long lds_,
+                                                           float* __restrict__ theta, long ldt, int out_bf16) {
   __shared__ float red[8];
   __shared__ float bc;
   long r = blockIdx.x;
@@ -222,16 +225,18 @@ __global__ __launch_bounds__(256) void relu_softmax_kernel(const float* __restri
     float a0 = z[r * ldz + c];
     if (apply_relu) a0 = fmaxf(a0, 0.f);
     float a = fs ? a0 * sigmoidf_(fs[c]) : a0;
-    scale[r * lds_ + c] = expf(a - m) * inv;
+    float sv = expf(a - m) * inv;
+    if (out_bf16) ((__bf16*)scale)[r * lds_ + c] = (__bf16)sv;
+    else ((float*)scale)[r * lds_ + c] = sv;
     if (theta) theta[r * ldt + c] = expf(a0);
   }
 }
 
 extern "C" int scp_relu_softmax_rows(const float* z, long ldz, int rows, int cols, const float* fs, int apply_relu,
-                                     float* scale, long lds_, float* theta, long ldt, void* stream_) {
+                                     void* scale, long lds_, float* theta, long ldt, int out_bf16, void* stream_) {
   SCP_CHECK(z && scale && rows > 0 && cols > 0, SCP_ERR_ARG, "scp_relu_softmax_rows: bad argument");
   hipLaunchKernelGGL(relu_softmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream_, z, ldz, cols, fs, apply_relu,
-                     scale, lds_, theta, ldt);
+                     scale, lds_, theta, ldt, out_bf16);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

@@ -14,22 +14,42 @@ import pandas as pd
 import scipy.sparse as sp
 
 
+def _value_range(X):
+    """(min, max) of a dense or scipy-sparse matrix without densifying it."""
+    return X.min(), X.max()
+
+
+def _binary_problem(lo, hi):
+    return lo < 0 or hi > 1
+
+
 def check_distribution(name, obj, dist):
-    """utils.py:341-353.  'ber': anything outside [0, 1] is binarised in place (X > 0); 'zinb'/'nb': negative
-    values raise, non-integer dtype warns; 'gau': the reference raises when every value is positive (its test is
-    `X.min() > 0`; kept as is)."""
+    """Counterpart of utils.py:341-353: validates one modality's matrix against the likelihood chosen for it.
+
+      'ber'         values outside [0, 1] -> the matrix is replaced, in place, by its 0/1 indicator (X > 0), with a notice
+      'zinb' / 'nb' any negative value is an error; a non-integer dtype only warns
+      'gau'         an error when the smallest value is positive (the upstream test is `X.min() > 0`; kept, although its
+                    message speaks of non-negative values)
+    Other distribution names are not checked, as upstream."""
+    lo, hi = _value_range(obj.X)
+    family = {"ber": "Bernoulli", "zinb": "(Zero-Inflated) Negative Binomial", "nb": "(Zero-Inflated) Negative Binomial",
+              "gau": "Gaussian"}.get(dist)
+    if family is None:
+        return
+    head = f"{family} distribution was set for {name} data, but {name} data"
     if dist == "ber":
-        if obj.X.min() < 0 or obj.X.max() > 1:
-            print(f"Bernoulli distribution was set for {name} data, but {name} data is not binary. Converting to binary...")
+        if _binary_problem(lo, hi):
+            print(f"{head} is not binary. Converting to binary...")
             obj.X = (obj.X > 0).astype(int)
-    elif dist in ("zinb", "nb"):
-        if obj.X.min() < 0:
-            raise ValueError(f"(Zero-Inflated) Negative Binomial distribution was set for {name} data, but {name} data has negative values.")
-        elif obj.X.dtype != "int":
-            warnings.warn(f"(Zero-Inflated) Negative Binomial distribution was set for {name} data, but {name} data is not integer.")
-    elif dist == "gau":
-        if obj.X.min() > 0:
-            raise ValueError(f"Gaussian distribution was set for {name} data, but {name} data has non-negative values.")
+        return
+    if dist == "gau":
+        if lo > 0:
+            raise ValueError(f"{head} has non-negative values.")
+        return
+    if lo < 0:
+        raise ValueError(f"{head} has negative values.")
+    if obj.X.dtype != "int":
+        warnings.warn(f"{head} is not integer.")
 
 
 def _concat_features(a, b):
@@ -53,23 +73,24 @@ def _concat_features(a, b):
 
 def merge_paired_data(paired_objects=[None, None], modality_names=["Gene Expression", "Peaks"],
                       modality_distributions=["zinb", "ber"]):
-    """utils.py:356-366: tag each object's features with its modality name and distribution, check / binarise, and
-    concatenate the two along the feature axis."""
-    paired_obj_dict = dict(zip(modality_names, paired_objects))
-    paired_dist_dict = dict(zip(modality_names, modality_distributions))
-    for name, obj in paired_obj_dict.items():
-        obj.var["modality"] = name
+    """Counterpart of utils.py:356-366: one paired object from two single-modality ones.  Each object's `.var` gets the
+    columns 'modality' (its name) and 'modality_distribution', its matrix is validated / binarised by
+    check_distribution, and the two are joined along the feature axis over their common cells."""
+    if not (len(paired_objects) == len(modality_names) == len(modality_distributions) == 2):
+        raise ValueError("merge_paired_data expects two objects, two modality names and two distributions")
+    for obj, name, dist in zip(paired_objects, modality_names, modality_distributions):
         print(f"processing modality: {name}")
-        obj.var["modality_distribution"] = paired_dist_dict[name]
-        check_distribution(name, obj, paired_dist_dict[name])
-    a, b = paired_obj_dict[modality_names[0]], paired_obj_dict[modality_names[1]]
+        obj.var["modality"] = name
+        obj.var["modality_distribution"] = dist
+        check_distribution(name, obj, dist)
+    first, second = paired_objects
     try:
         import anndata
     except ImportError:
         anndata = None
-    if anndata is not None and isinstance(a, anndata.AnnData):
-        return anndata.concat([a.T, b.T], merge="same").T
-    return _concat_features(a, b)
+    if anndata is not None and isinstance(first, anndata.AnnData):
+        return anndata.concat([first.T, second.T], merge="same").T
+    return _concat_features(first, second)
 
 
 def _sample_per_group(frame, batch_key, frac, seed):

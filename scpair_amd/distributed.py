@@ -30,6 +30,8 @@ class GradSync:
         self.compress = compress
         self._pending = []
         self._backend = dist.get_backend(group)
+        from . import ops
+        ops.set_seed_rank(self.rank)          # dropout masks differ between the shards of a global batch
 
     # -- batch sharding --------------------------------------------------------------------------------------
     def shard(self, rows):
@@ -51,7 +53,13 @@ class GradSync:
 
     def broadcast(self, tensors, src=0):
         for t in tensors:
-            dist.broadcast(t.data if hasattr(t, "data") else t, src=src, group=self.group)
+            t = t.data if hasattr(t, "data") else t
+            if self._backend != "nccl" and t.is_cuda:      # staged through host like the other gloo + GPU collectives
+                h = t.detach().cpu()
+                dist.broadcast(h, src=src, group=self.group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src, group=self.group)
 
     def make_sink(self, params):
         """One flat bf16 exchange buffer for the wide first-layer weights `params` (precision 'bf16'): their
@@ -115,10 +123,58 @@ class GradSync:
         tot = self._sum(nv.clone())
         w = (nv / tot).to(torch.float32)
         grads = [p.grad for p in params if p.grad is not None]
-        for g in grads:
-            g.mul_(w)
+        if grads:
+            torch._foreach_mul_(grads, w.reshape(()))
         self.start_all_reduce(grads)
         self.finish()
+
+    # -- one optimisation step's exchange (what the trainers call) ------------------------------------------------
+    def some_rank_empty(self, n_global_rows: int) -> bool:
+        """True when shard() leaves at least one rank without rows (global batch smaller than the world); every rank
+        computes the same answer from the global batch size."""
+        return int(n_global_rows) < self.world
+
+    def _align_grads(self, params, sink):
+        """Ranks with an empty shard ran no backward and hold no gradients: agree (MAX all-reduce of a presence mask) on
+        which parameters carry one and supply zeros where this rank has none, so every rank enters the same
+        collectives with the same buckets."""
+        sink_ids = {} if sink is None else {id(h.param): h for h in sink[1]}
+        have = [1.0 if (p.grad is not None or (id(p) in sink_ids and sink_ids[id(p)].written)) else 0.0 for p in params]
+        dev = params[0].device if self._backend == "nccl" else "cpu"
+        mask = torch.tensor(have, dtype=torch.float32, device=dev)
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        mask = mask.cpu().tolist()
+        zero_sink = False
+        for p, f, h in zip(params, mask, have):
+            if f > 0 and h == 0:
+                if id(p) in sink_ids:
+                    zero_sink = True
+                else:
+                    p.grad = torch.zeros_like(p)
+        if zero_sink:
+            sink[0].zero_()
+            for h_ in sink[1]:
+                h_.written = True
+
+    def exchange(self, params, n_valid, loss, sink=None, some_rank_empty=False):
+        """After backward() on this rank's shard: one small collective for the step's scalars (this rank's number of
+        valid label elements and its loss), gradients scaled by n_r / n_total in one multi-tensor launch, the bucketed
+        SUM all-reduce.  `loss` None / n_valid 0: this rank's shard was empty.  Returns the global-batch loss."""
+        dev = params[0].device
+        nv = torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(())
+        lv = torch.zeros((), dtype=torch.float64, device=dev) if loss is None else loss.detach().double().reshape(())
+        v = self._sum(torch.stack([nv, lv * nv]))
+        w = (nv / v[0]).to(torch.float32)
+        if some_rank_empty:
+            self._align_grads(params, sink)
+        grads = [p.grad for p in params if p.grad is not None]
+        if grads:
+            torch._foreach_mul_(grads, w)
+        if sink is not None and any(h.written for h in sink[1]):
+            sink[0].mul_(w.to(sink[0].dtype))      # exact for equal shards on 2^k ranks (w = 1 / world)
+        self.start_all_reduce(grads, sink=sink)
+        self.finish()
+        return (v[1] / v[0]).to(torch.float32)
 
     def weighted_mean(self, value, n_valid):
         dev = value.device

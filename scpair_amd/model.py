@@ -119,8 +119,15 @@ class Output_Module_Ber(nn.Module):
         reference; used by predict().  Training uses fused_loss(), which never materialises them."""
         latent_rep = _cat_cov(latent_rep, output_batch)
         self.output_temp = self.output_layer(latent_rep)
-        output_px = torch.sigmoid(self.output_temp)
         lrow = self._lrow(lib, latent_lib)
+        if not torch.is_grad_enabled() and self.output_temp.is_cuda:
+            # inference: the fused head kernel (one pass per returned tensor, no intermediate products)
+            fs = self.feature_scalar if self.feature_factor == True else None  # noqa: E712
+            output_px = ops.ber_prob(self.output_temp)
+            output_result = output_px if (lrow is None and fs is None) else ops.ber_prob(self.output_temp, lrow, fs)
+            return (output_result, output_px, None if lrow is None else torch.sigmoid(lrow),
+                    None if fs is None else torch.sigmoid(fs))
+        output_px = torch.sigmoid(self.output_temp)
         if lrow is not None:
             output_sample_factor = torch.sigmoid(lrow)
             output_result = output_px * output_sample_factor
@@ -133,6 +140,14 @@ class Output_Module_Ber(nn.Module):
         else:
             output_feature_factor = None
         return output_result, output_px, output_sample_factor, output_feature_factor
+
+    @torch.no_grad()
+    def predict_head(self, latent_rep, output_batch, lib, latent_lib, out_dtype=torch.float32):
+        """forward(...)[0] only (what predict() keeps, model.py:584-590): logits GEMM + one head kernel, optionally
+        written as bf16."""
+        z = self.output_layer(_cat_cov(latent_rep, output_batch))
+        fs = self.feature_scalar if self.feature_factor == True else None  # noqa: E712
+        return ops.ber_prob(z, self._lrow(lib, latent_lib), fs, out_dtype=out_dtype)
 
     def fused_loss(self, latent_rep, output_batch, lib, latent_lib, labels, likelihood="ber"):
         """binarized_loss(labels, forward(...)[0]) in one kernel pass with its backward (no [cells x peaks] tensor)."""
@@ -171,11 +186,21 @@ class Output_Module_Raw(nn.Module):
 
     def forward(self, latent_rep, output_batch, lib, latent_lib):
         latent_rep = _cat_cov(latent_rep, output_batch)
-        px_mu = self.output_mean(latent_rep)
-        if self.feature_factor == True:  # noqa: E712
-            px_mu_scale = self.scale_function(px_mu * torch.sigmoid(self.feature_scalar))
+        hip_head = (not torch.is_grad_enabled()) and latent_rep.is_cuda
+        theta_k = None
+        if hip_head:
+            # inference: relu -> [feature factor] -> row softmax (and exp dispersion) in one row kernel
+            z = self.output_mean[0](latent_rep)
+            px_mu_scale, theta_k = ops.relu_softmax_rows(
+                z, self.feature_scalar if self.feature_factor == True else None, True,  # noqa: E712
+                want_theta=(self.dispersion == "feature-cell"))
+            px_mu = torch.relu_(z) if self.zero_inflated == True else None  # noqa: E712   (operand of the pi layer)
         else:
-            px_mu_scale = self.scale_function(px_mu)
+            px_mu = self.output_mean(latent_rep)
+            if self.feature_factor == True:  # noqa: E712
+                px_mu_scale = self.scale_function(px_mu * torch.sigmoid(self.feature_scalar))
+            else:
+                px_mu_scale = self.scale_function(px_mu)
         if self.sample_factor == True:  # noqa: E712
             px_mu_rate = lib * px_mu_scale
         elif latent_lib is not None:
@@ -186,12 +211,20 @@ class Output_Module_Raw(nn.Module):
         if self.dispersion == "feature":
             px_theta = torch.exp(self.output_inverse_dispersion)
         elif self.dispersion == "feature-cell":
-            px_theta = torch.exp(px_mu)
+            px_theta = theta_k if hip_head else torch.exp(px_mu)
         if self.zero_inflated == True:  # noqa: E712
             px_pi = self.output_dropout(px_mu)
         else:
             px_pi = None
         return px_mu_scale, px_theta, px_mu_rate, px_pi
+
+    @torch.no_grad()
+    def predict_head(self, latent_rep, output_batch, lib, latent_lib, out_dtype=torch.float32):
+        """forward(...)[0] only, the normalised mean `px_mu_scale` that predict() keeps (model.py:584-590): logits
+        GEMM + one row kernel, optionally written as bf16."""
+        z = self.output_mean[0](_cat_cov(latent_rep, output_batch))
+        fs = self.feature_scalar if self.feature_factor == True else None  # noqa: E712
+        return ops.relu_softmax_rows(z, fs, True, out_dtype=out_dtype)[0]
 
     def fused_loss(self, latent_rep, output_batch, lib, latent_lib, labels, likelihood="nb"):
         """raw_loss(labels, *forward(...)): likelihood 'nb' in three fused decoder passes (row softmax statistics,
@@ -606,7 +639,9 @@ class scPair_object():
         n = xcsr.n_rows
         num = torch.zeros((), dtype=torch.float64, device=self.device)
         den = torch.zeros((), dtype=torch.float64, device=self.device)
-        for r0 in range(0, n, self.val_chunk):
+        for ci, r0 in enumerate(range(0, n, self.val_chunk)):
+            if self.grad_sync is not None and ci % self.grad_sync.world != self.grad_sync.rank:
+                continue                          # data parallel: every rank takes every world-th chunk
             rows = np.arange(r0, min(n, r0 + self.val_chunk))
             tx = BatchTiles(xcsr, rows, want_lib=False)
             ty = BatchTiles(ycsr, rows, want_lib=True)
@@ -666,9 +701,17 @@ class scPair_object():
         return mapped_embeddings, df_mapped_embeddings
 
     @torch.no_grad()
-    def predict(self):
-        """model.py:558-591: decoder outputs [0] for every split (dense numpy arrays), lib = [1]."""
+    def predict(self, out_dtype=None, topk=None):
+        """model.py:558-591: decoder outputs [0] for every split (dense numpy arrays), lib = [1].
+
+        Atlas-scale options (not in the reference, whose dense fp32 result is 4 B x cells x features on the host):
+        `out_dtype=torch.bfloat16` makes the head kernels write bf16, halving the device-to-host copy (arrays come back
+        as torch.bfloat16 tensors, numpy has no such dtype); `topk=k` keeps the k largest predictions per cell and
+        returns {'values': [n, k], 'indices': [n, k]} per split."""
         predictions = {}
+        od = torch.float32 if out_dtype is None else out_dtype
+        if od not in (torch.float32, torch.bfloat16):
+            raise ValueError("predict: out_dtype must be None, torch.float32 or torch.bfloat16")
         self._precision()
         for input_modality in self.modality_names:
             output_modality = self._other(input_modality)
@@ -693,12 +736,24 @@ class scPair_object():
                     icov = self._cov_dev(d, f'{input_modality}_{split}_cov')
                     _, lat = self._encode(encoder_cal, self._csr(d, f'{input_modality}_{split}_mtx', as_input=True), icov, want_lib=True)
                 lib = torch.ones(1, device=self.device) if dist in ['ber', 'nb', 'zinb'] else None
-                outs = []
+                outs, idxs = [], []
                 for r0 in range(0, emb.shape[0], self.val_chunk):
                     sl = slice(r0, r0 + self.val_chunk)
-                    pred = decoder_cal(emb[sl], None if ocov is None else ocov[sl], lib, None if lat is None else lat[sl])
-                    outs.append((pred if dist == 'gau' else pred[0]).cpu())
-                predictions[output_modality + f"_{split}"] = torch.cat(outs, 0).numpy()
+                    args = (emb[sl], None if ocov is None else ocov[sl], lib, None if lat is None else lat[sl])
+                    if dist != 'gau' and hasattr(decoder_cal, 'predict_head'):
+                        pred = decoder_cal.predict_head(*args, out_dtype=od)       # HIP head kernels, [0] only
+                    else:
+                        pred = decoder_cal(*args)
+                        pred = (pred if dist == 'gau' else pred[0]).to(od)
+                    if topk is not None:
+                        v, ix = torch.topk(pred.float(), int(topk), dim=1)
+                        outs.append(v.to(od).cpu()); idxs.append(ix.cpu())
+                    else:
+                        outs.append(pred.cpu())
+                key = output_modality + f"_{split}"
+                vals = torch.cat(outs, 0)
+                vals = vals.numpy() if od == torch.float32 else vals
+                predictions[key] = vals if topk is None else {"values": vals, "indices": torch.cat(idxs, 0).numpy()}
         return predictions
 
     # -- training ------------------------------------------------------------------------------------------
@@ -750,17 +805,44 @@ class scPair_object():
                   {'params': nodecay_e, 'weight_decay': 0, 'lr': lr},
                   {'params': nodecay_d, 'weight_decay': 0, 'lr': lr}]
         opt = ops.FusedAdamW([g for g in groups if len(g['params']) > 0])
-        if self.grad_sync is None and self.fuse_optimizer:
-            # single process: the AdamW step of the wide sparse first-layer weights runs inside their
-            # weight-gradient kernel (precision 'bf16', no covariate block; other cases keep the two-kernel path)
-            firsts = []
-            for seq in (getattr(encoder, 'hidden_rep', None), getattr(encoder, 'hidden_lib', None)):
-                while isinstance(seq, nn.Sequential) and len(seq) > 0:
-                    seq = seq[0]
-                if isinstance(seq, nn.Linear):
-                    firsts.append(seq.weight)
-            opt.fuse_first_layer(*firsts)
+        self._wire_first_layers(opt, encoder, ('hidden_rep', 'hidden_lib'))
         return opt
+
+    def _wire_first_layers(self, opt, encoder, names):
+        """The wide sparse first-layer weights of `encoder`.  Single process: their AdamW step runs inside their
+        weight-gradient kernel (precision 'bf16', no covariate block; other cases keep the two-kernel path).  Data
+        parallel with a bf16 exchange (GradSync(compress=True), precision 'bf16'): the kernel writes dW as bf16
+        straight into the exchange buffer that the all-reduce sums and the optimiser reads."""
+        firsts = []
+        for seq in (getattr(encoder, n_, None) for n_ in names):
+            while isinstance(seq, nn.Sequential) and len(seq) > 0:
+                seq = seq[0]
+            if isinstance(seq, nn.Linear):
+                firsts.append(seq.weight)
+        opt._dp_sink = None
+        if self.grad_sync is None:
+            if self.fuse_optimizer:
+                opt.fuse_first_layer(*firsts)
+        elif self.grad_sync.compress and ops.get_precision() == "bf16" and firsts and all(p.is_cuda for p in firsts):
+            opt._dp_sink = self.grad_sync.make_sink(firsts)
+        return firsts
+
+    def _dp_step(self, loss, n_valid, optimizer, some_rank_empty=False):
+        """Data-parallel tail of one optimisation step: backward on this rank's shard (loss None: empty shard), the
+        gradient exchange, the identical AdamW step on every rank.  Returns the global-batch loss."""
+        optimizer.zero_grad()
+        if loss is not None:
+            loss.backward()
+        params = [p for g in optimizer.param_groups for p in g['params']]
+        gl = self.grad_sync.exchange(params, n_valid, loss, sink=getattr(optimizer, '_dp_sink', None),
+                                     some_rank_empty=some_rank_empty)
+        optimizer.step()
+        return gl
+
+    def _check_dp(self, *modules):
+        if self.grad_sync is not None and any(isinstance(m, nn.BatchNorm1d) for mod in modules for m in mod.modules()):
+            raise NotImplementedError("data-parallel training with batchnorm=True needs synchronised batch statistics, "
+                                      "which are not implemented: use batchnorm=False (the constructor default)")
 
     def train_predicting_networks(self, train_data_dict, val_data_dict, test_data_dict, batch_replay=None):
         """model.py:603-812.  `batch_replay`: optional {direction_index: [row-id arrays]} to replay a recorded batch
@@ -787,6 +869,7 @@ class scPair_object():
             optimizer = self._make_optimizer(encoder, decoder)
             scheduler = self.get_scheduler(optimizer)
             if self.grad_sync is not None:
+                self._check_dp(encoder, decoder)
                 self.grad_sync.broadcast(list(encoder.parameters()) + list(decoder.parameters()) +
                                          list(encoder.buffers()) + list(decoder.buffers()))
             set_seed(self.SEED)
@@ -812,8 +895,13 @@ class scPair_object():
                     batches = (b[0].numpy() for b in loader)
                 step_losses = []
                 for rows in batches:
+                    empty_somewhere = False
                     if self.grad_sync is not None:
+                        empty_somewhere = self.grad_sync.some_rank_empty(len(rows))
                         rows = self.grad_sync.shard(rows)
+                        if len(rows) == 0:            # global batch smaller than the world: join the collectives only
+                            step_losses.append(self._dp_step(None, 0.0, optimizer, True))
+                            continue
                     rows = np.asarray(rows, dtype=np.int64)
                     rows_dev = torch.from_numpy(rows).to(self.device)          # one upload, shared by both modalities
                     if stepper is not None and stepper.wants(rows):
@@ -826,7 +914,7 @@ class scPair_object():
                     else:
                         ty = BatchTiles(ytr, rows_dev, want_lib=use_lib, rows_host=rows)
                         lib = ty.lib.reshape(-1, 1) if use_lib else None
-                    loss = self._train_step(tx, ty, lib, encoder, decoder, optimizer, dist, c)
+                    loss = self._train_step(tx, ty, lib, encoder, decoder, optimizer, dist, c, empty_somewhere)
                     step_losses.append(loss)
                 hist["train_loss"].extend(step_losses)
                 val_total_loss = float(self._eval_split(encoder, decoder, xva, yva, cva, use_lib, dist).item())
@@ -858,20 +946,16 @@ class scPair_object():
         self.encoder_dict, self.decoder_dict = encoder_dict, decoder_dict
         return encoder_dict, decoder_dict
 
-    def _train_step(self, tx, ty, lib, encoder, decoder, optimizer, dist, cov):
+    def _train_step(self, tx, ty, lib, encoder, decoder, optimizer, dist, cov, some_rank_empty=False):
         if self.grad_sync is None:
             return train_net(tx, ty, lib, encoder, decoder, optimizer, likelihood_type=dist, add_cov=cov is not None,
                              input_batch=cov, output_batch=cov)
         from .utils import _predictor_loss
         loss = _predictor_loss(tx, ty, lib, encoder, decoder, dist, cov is not None, cov, cov)
-        optimizer.zero_grad()
-        loss.backward()
         # weight of this rank's mean in the global-batch mean = its share of the valid label elements
         n_valid = float(ty.shape[0] * ty.shape[1]) if not isinstance(ty, BatchTiles) or dist != "ber" else \
             (float(ty.B * ty.F) - ty.nnan.double()[0])
-        self.grad_sync.all_reduce_grads([p for g in optimizer.param_groups for p in g['params']], n_valid)
-        optimizer.step()
-        return self.grad_sync.weighted_mean(loss.detach(), n_valid)
+        return self._dp_step(loss, n_valid, optimizer, some_rank_empty)
 
     def train_bidirectional_mapping(self):
         """model.py:813-924."""
@@ -898,12 +982,27 @@ class scPair_object():
                       {'params': nodecay_param, 'weight_decay': 0, 'lr': self.mapping_learning_rate}]
             optimizer = ops.FusedAdamW([g for g in groups if len(g['params']) > 0])
             scheduler = self.get_scheduler(optimizer)
+            if self.grad_sync is not None:
+                self._check_dp(mapping_network)
+                self.grad_sync.broadcast(list(mapping_network.parameters()) + list(mapping_network.buffers()))
             patience, no_improve, min_val = self.early_stopping_patience, 0, np.inf
             hist = {"train_loss": [], "val_loss": []}
             ckpt = None
             for epoch in range(self.max_epochs):
                 mapping_network.train()
                 for (idx,) in loader:
+                    if self.grad_sync is not None:
+                        # data parallel: this rank's slice of the global batch, count-weighted gradient exchange
+                        empty_somewhere = self.grad_sync.some_rank_empty(len(idx))
+                        idx = torch.from_numpy(self.grad_sync.shard(idx.numpy()))
+                        if len(idx) == 0:
+                            hist["train_loss"].append(self._dp_step(None, 0.0, optimizer, True))
+                            continue
+                        idx = idx.to(self.device)
+                        training_loss = scaled_loss(yout[idx], mapping_network(xin[idx]))
+                        hist["train_loss"].append(self._dp_step(training_loss, float(len(idx) * embedding_dim), optimizer,
+                                                                empty_somewhere))
+                        continue
                     idx = idx.to(self.device)
                     pred_emb = mapping_network(xin[idx])
                     training_loss = scaled_loss(yout[idx], pred_emb)
@@ -937,17 +1036,45 @@ class scPair_object():
         self.mapping_dict = mapping_dict
         return mapping_dict
 
+    def _augment_covariates(self, unimodal_scobj, unimodal_cov, n_uni, n_cov):
+        """model.py:936-947.  Upstream, the only covariate combination that runs is "paired data with covariates,
+        unimodal data without": the unimodal cells then get an all-zero covariate block.  A unimodal covariate list
+        without paired covariates raises like upstream.  Equal non-empty lists fail upstream (`unimodal_cov_dummy` is
+        never assigned, model.py:950); here they are encoded like data_loader_builder does (one-hot / z-score), aligned
+        to the paired data's covariate columns (levels the paired data never saw are dropped, missing ones are zero)."""
+        if unimodal_cov is not None and self.cov is None:
+            raise ValueError('Unimodal data have covariate matrix while multimodal data do not')
+        if self.cov is None:
+            return None
+        if unimodal_cov is None:
+            self._say('Using multimodal cov for unimodal data, and set unimodal cov to all zeros during scPair_augment training')
+            return torch.zeros((n_uni, n_cov), dtype=torch.float32, device=self.device)
+        if list(unimodal_cov) != list(self.cov):
+            raise ValueError('unimodal_cov must be None or the paired data\'s covariate list '
+                             '(upstream drops the unimodal covariates here and then fails on the encoder input width)')
+        if getattr(self, 'cov_dummy', None) is None or not hasattr(unimodal_scobj, 'obs'):
+            raise ValueError('unimodal covariates need data_loader_builder() (covariate columns) and unimodal_scobj.obs')
+        import pandas as pd
+        obs = unimodal_scobj.obs
+        parts = []
+        for c in unimodal_cov:
+            if obs[c].dtype.name in ('category', 'object'):
+                parts.append(pd.get_dummies(obs[c]).astype(int))
+            else:
+                parts.append(((obs[c] - obs[c].mean()) / obs[c].std()).to_frame())
+        dm = pd.concat(parts, axis=1).reindex(columns=self.cov_dummy.columns, fill_value=0)
+        return torch.tensor(dm.values.astype(np.float32), device=self.device)
+
     def augment(self, unimodal_scobj, unimodal_modalities, unimodal_cov=None):
         """model.py:925-1036: fine-tune a copy of the trained encoder on unimodal cells to regress its own embeddings
         (dropout active), early-stopped on the bimodal train+val cells.  `unimodal_scobj` needs `.X` (scipy sparse,
-        ndarray or DeviceCSR); covariates other than None/None are not supported without AnnData."""
+        ndarray or DeviceCSR) and, for covariates, `.obs`.  With `grad_sync` every global batch is sliced by rank and
+        the gradients are exchanged like in train_predicting_networks."""
         self._precision()
         self.unimodal_scobj, self.unimodal_modalities, self.unimodal_cov = unimodal_scobj, unimodal_modalities, unimodal_cov
         self.unimodal_modality_names = list(unimodal_modalities.keys())
         if not set(self.unimodal_modality_names).issubset(self.modalities.keys()):
             raise ValueError('Unimodal data should have the same modality as one of the multimodal data')
-        if self.cov is not None or unimodal_cov is not None:
-            raise NotImplementedError("augment() with covariates needs the AnnData plumbing (model.py:936-947)")
         name = self.unimodal_modality_names[0]
         other = [mn for mn in self.modalities.keys() if mn != name][0]
         X = unimodal_scobj.X if hasattr(unimodal_scobj, "X") else unimodal_scobj
@@ -957,29 +1084,53 @@ class scPair_object():
             uni = uni.with_transform(*((tf[0], tf[1]) if isinstance(tf, (tuple, list)) else (tf, 1e4)))
         btr = self._csr(self.data_loader_dict_train, name + '_train_mtx', as_input=True)
         bva = self._csr(self.data_loader_dict_val, name + '_val_mtx', as_input=True)
-        bte = self._csr(self.data_loader_dict_test, name + '_test_mtx', as_input=True) \
-            if hasattr(self, 'data_loader_dict_test') else None
+        has_test = getattr(self, 'data_loader_dict_test', None) is not None
+        bte = self._csr(self.data_loader_dict_test, name + '_test_mtx', as_input=True) if has_test else None
+        ctr = self._cov_dev(self.data_loader_dict_train, name + '_train_cov')
+        cva = self._cov_dev(self.data_loader_dict_val, name + '_val_cov')
+        cte = self._cov_dev(self.data_loader_dict_test, name + '_test_cov') if has_test else None
+        cuni = self._augment_covariates(unimodal_scobj, unimodal_cov, uni.n_rows, 0 if ctr is None else ctr.shape[1])
         enc = copy.deepcopy(self.encoder_dict[name + ' to ' + other]).to(self.device)
         enc.eval()
-        uni_label = self._encode(enc, uni, None)
-        btr_label, bva_label = self._encode(enc, btr, None), self._encode(enc, bva, None)
+        uni_label = self._encode(enc, uni, cuni)
+        btr_label, bva_label = self._encode(enc, btr, ctr), self._encode(enc, bva, cva)
         set_seed(self.SEED)
         loader = _index_loader(uni.n_rows, self.batch_size)
         optimizer = ops.FusedAdamW(enc.parameters(), lr=self.learning_rate_prediction, weight_decay=self.L2_lambda)
+        if cuni is None:
+            self._wire_first_layers(optimizer, enc, ('hidden_rep',))     # only latent_rep is trained (model.py:993)
+        if self.grad_sync is not None:
+            self._check_dp(enc)
+            self.grad_sync.broadcast(list(enc.parameters()) + list(enc.buffers()))
         patience, no_improve, min_val = self.early_stopping_patience, 0, np.inf
         self.augment_encoder_ckpt = None
+        emb_dim = self.hidden_layer[-1]
+        hist = {"val_loss": []}
         for epoch in range(self.max_epochs):
             enc.train()
             for (idx,) in loader:
                 rows = idx.numpy()
-                pred = enc(BatchTiles(uni, rows, want_lib=False), None)[0]
-                loss = scaled_loss(uni_label[idx.to(self.device)], pred)
+                empty_somewhere = False
+                if self.grad_sync is not None:
+                    empty_somewhere = self.grad_sync.some_rank_empty(len(rows))
+                    rows = self.grad_sync.shard(rows)
+                    if len(rows) == 0:
+                        self._dp_step(None, 0.0, optimizer, True)
+                        continue
+                rows_dev = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(self.device)
+                pred = enc(BatchTiles(uni, rows_dev, want_lib=False, rows_host=rows),
+                           None if cuni is None else cuni[rows_dev])[0]
+                loss = scaled_loss(uni_label[rows_dev], pred)
+                if self.grad_sync is not None:
+                    self._dp_step(loss, float(len(rows) * emb_dim), optimizer, empty_somewhere)
+                    continue
                 optimizer.zero_grad()
                 loss.backward()
                 optimizer.step()
             with torch.no_grad():
-                pv = torch.cat([self._encode(enc, btr, None), self._encode(enc, bva, None)], 0)
+                pv = torch.cat([self._encode(enc, btr, ctr), self._encode(enc, bva, cva)], 0)
                 val_total_loss = float(scaled_loss(torch.cat([btr_label, bva_label], 0), pv).item())
+            hist["val_loss"].append(val_total_loss)
             if val_total_loss < min_val:
                 no_improve, min_val = 0, val_total_loss
                 self.augment_encoder_ckpt = copy.deepcopy(enc)
@@ -988,6 +1139,7 @@ class scPair_object():
             if epoch > 1 and no_improve == patience:
                 self._say("Early Stopped!")
                 break
+        self.history['scPair_augment: ' + name + ' to ' + other] = hist
         self.augment_encoder_ckpt.eval()
         if self.save_model is True:
             if self.save_path is None:
@@ -995,8 +1147,9 @@ class scPair_object():
             torch.save(self.augment_encoder_ckpt, self.save_path + '/augment_encoder_' + name + '_to_' + other + '.pt')
         self.augment_encoder_dict = {'scPair_augment: ' + name + ' to ' + other: copy.deepcopy(self.augment_encoder_ckpt)}
         augment_emb = {}
-        for split, csr in (('unimodal_train', uni), ('bimodal_train', btr), ('bimodal_val', bva), ('bimodal_test', bte)):
+        for split, csr, cv in (('unimodal_train', uni, cuni), ('bimodal_train', btr, ctr), ('bimodal_val', bva, cva),
+                               ('bimodal_test', bte, cte)):
             if csr is None:
                 continue
-            augment_emb[name + f'_{split}'] = self._encode(self.augment_encoder_ckpt, csr, None).cpu().numpy()
+            augment_emb[name + f'_{split}'] = self._encode(self.augment_encoder_ckpt, csr, cv).cpu().numpy()
         return self.augment_encoder_dict, augment_emb

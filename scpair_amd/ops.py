@@ -39,9 +39,14 @@ def set_fused_timer(sink):
     _cfg["fused_timer"] = sink
 
 
+def set_seed_rank(rank: int):
+    """Data parallelism: mixes the rank into every dropout seed drawn from now on (scpair_amd.distributed.GradSync)."""
+    _cfg["seed_rank"] = int(rank)
+
+
 def next_seed() -> int:
     _cfg["seed_ctr"] += 1
-    return ((torch.initial_seed() & 0xFFFFFFFF) << 24) + _cfg["seed_ctr"]
+    return ((torch.initial_seed() & 0xFFFFFFFF) << 24) + _cfg["seed_ctr"] + (_cfg.get("seed_rank", 0) << 56)
 
 
 class StepState:
@@ -701,26 +706,34 @@ def reparam_kl(mu, sraw, eps):
 # ------------------------------------------------------------------------------------------------
 # inference heads
 # ------------------------------------------------------------------------------------------------
-def ber_prob(z, lrow=None, fs=None):
+def ber_prob(z, lrow=None, fs=None, out_dtype=torch.float32):
+    """sigmoid(z) [* sigmoid(lrow)] [* sigmoid(fs)] (model.py:173-189), fp32 or bf16 output; inference only."""
     L = _lib.lib()
     z = _f32c(z)
+    _lib.require_cuda(z, lrow, fs)
     rows, cols = z.shape
-    out = torch.empty_like(z)
+    out = torch.empty((rows, cols), dtype=out_dtype, device=z.device)
     lr = None if lrow is None else _f32c(lrow).reshape(-1)
+    if lr is not None and lr.numel() not in (1, rows):
+        raise ValueError("ber_prob: the sample factor needs 1 or one entry per row")
     _lib.check(L.scp_ber_prob(z.data_ptr(), cols, rows, cols, _lib.ptr(lr), 0 if lr is None else lr.numel(),
-                              _lib.ptr(_f32c(fs)), out.data_ptr(), cols, _lib.stream()), "scp_ber_prob")
+                              _lib.ptr(_f32c(fs)), out.data_ptr(), cols, int(out_dtype == torch.bfloat16), _lib.stream()),
+               "scp_ber_prob")
     return out
 
 
-def relu_softmax_rows(z, fs=None, apply_relu=True, want_theta=False):
+def relu_softmax_rows(z, fs=None, apply_relu=True, want_theta=False, out_dtype=torch.float32):
+    """scale = softmax(relu(z) [* sigmoid(fs)]) per row and, on request, theta = exp(relu(z)) (model.py:238-252);
+    inference only."""
     L = _lib.lib()
     z = _f32c(z)
+    _lib.require_cuda(z, fs)
     rows, cols = z.shape
-    scale = torch.empty_like(z)
+    scale = torch.empty((rows, cols), dtype=out_dtype, device=z.device)
     theta = torch.empty_like(z) if want_theta else None
     _lib.check(L.scp_relu_softmax_rows(z.data_ptr(), cols, rows, cols, _lib.ptr(_f32c(fs)), int(apply_relu),
-                                       scale.data_ptr(), cols, _lib.ptr(theta), cols, _lib.stream()),
-               "scp_relu_softmax_rows")
+                                       scale.data_ptr(), cols, _lib.ptr(theta), cols, int(out_dtype == torch.bfloat16),
+                                       _lib.stream()), "scp_relu_softmax_rows")
     return scale, theta
 
 

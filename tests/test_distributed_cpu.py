@@ -147,3 +147,70 @@ def test_bf16_exchange_buffer_written_by_the_kernels():
     np.testing.assert_allclose(b, np.arange(120.0).reshape(3, 40) * 3, rtol=2.0 ** -7)           # summed in bf16
     np.testing.assert_allclose(s, np.full(5, 1.5 + 0.75 * 2))      # 0.5 + 1.0 summed once, then summed again (1.5 * 2)
     assert untouched
+
+
+def _exchange_worker(rank, world, port, out, n_rows):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scpair_amd.distributed import GradSync
+    sync = GradSync(big=1000)
+    torch.manual_seed(0)
+    W1 = torch.nn.Parameter(torch.randn(40, 50)); b1 = torch.nn.Parameter(torch.randn(40)); W2 = torch.nn.Parameter(torch.randn(3, 40))
+    dead = torch.nn.Parameter(torch.randn(7))                # never receives a gradient (like the unused G x G layer)
+    params = [W1, b1, dead, W2]
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(10, 50, generator=g); Y = torch.randn(10, 3, generator=g)
+    Y[0, 1] = float("nan")                                     # a masked label: counts differ from rows x features
+    glob = np.arange(n_rows)
+    rows = sync.shard(glob)
+    some_empty = sync.some_rank_empty(len(glob))
+    loss, n_valid = None, 0.0
+    if len(rows):
+        x, y = X[rows], Y[rows]
+        pred = torch.relu(x @ W1.t() + b1) @ W2.t()
+        mask = ~torch.isnan(y)
+        loss = ((pred[mask] - y[mask]) ** 2).mean()
+        loss.backward()
+        n_valid = float(mask.sum())
+    gl = sync.exchange(params, n_valid, loss, some_rank_empty=some_empty)
+    out.put((rank, [None if p.grad is None else p.grad.clone().numpy() for p in params], float(gl), len(rows)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [1, 5])
+def test_exchange_with_ragged_and_empty_shards(n_rows):
+    """GradSync.exchange: one collective for (count, loss), count-weighted gradients; a global batch smaller than the
+    world leaves a rank without rows (n_train % batch_size < world, drop_last=False: model.py:713-717) -- it joins
+    the same collectives with zero gradients instead of hanging the others."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, out, n_rows)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([out.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    assert [r[3] for r in res] == ([1, 0] if n_rows == 1 else [3, 2])
+    torch.manual_seed(0)
+    W1 = torch.randn(40, 50, requires_grad=True); b1 = torch.randn(40, requires_grad=True); W2 = torch.randn(3, 40, requires_grad=True)
+    _ = torch.randn(7)
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(10, 50, generator=g)[:n_rows]; Y = torch.randn(10, 3, generator=g)[:n_rows]
+    Y[0, 1] = float("nan")
+    pred = torch.relu(X @ W1.t() + b1) @ W2.t()
+    mask = ~torch.isnan(Y)
+    loss = ((pred[mask] - Y[mask]) ** 2).mean()
+    loss.backward()
+    for rank, grads, gl, _ in res:
+        assert grads[2] is None                                  # the dead parameter stays without gradient everywhere
+        for ref, got in zip((W1, b1, W2), (grads[0], grads[1], grads[3])):
+            np.testing.assert_allclose(got, ref.grad.numpy(), rtol=1e-4, atol=1e-5)
+        assert abs(gl - float(loss)) < 1e-5 * abs(float(loss))

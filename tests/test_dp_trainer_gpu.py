@@ -20,41 +20,62 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import faulthandler
-    faulthandler.dump_traceback_later(100, exit=True)           # a stuck collective ends the rank with a traceback
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _train(grad_sync, batch, epochs, with_mapping, precision="fp32"):
     import scpair_amd as S
-    from scpair_amd.distributed import GradSync
     from tests.test_trajectory_gpu import _dicts
     d = U.load("traj_nb_ber")
     c = U.cfg(d, "cfg")
     tr, va, te = _dicts(c, d)
     obj = S.scPair_object(None, cov=None, modalities=c["modalities"], SEED=0, hidden_layer=c["hidden"], dropout_rate=0.0,
-                          batchnorm=False, layernorm=True, batch_size=c["batch"], max_epochs=3,
+                          batchnorm=False, layernorm=True, batch_size=batch, max_epochs=epochs,
                           device=torch.device("cuda:0"), save_model=False, zero_inflated=c["zero_inflated"],
-                          verbose=False, grad_sync=GradSync())
+                          verbose=False, grad_sync=grad_sync, use_mixed_precision=(precision == "bf16"))
     obj.train_predicting_networks(tr, va, te)
+    if with_mapping:
+        obj.reference_embeddings()
+        obj.train_bidirectional_mapping()
+    return {k: (list(map(float, v["train_loss"])), list(map(float, v["val_loss"]))) for k, v in obj.history.items()}
+
+
+def _worker(rank, world, port, out, batch, epochs, with_mapping, precision="fp32", compress=False):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)           # a stuck collective ends the rank with a traceback
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scpair_amd.distributed import GradSync
+    hist = _train(GradSync(compress=compress), batch, epochs, with_mapping, precision)
+    faulthandler.cancel_dump_traceback_later()
     if rank == 0:
-        out.put({k: (list(map(float, v["train_loss"])), list(map(float, v["val_loss"]))) for k, v in obj.history.items()})
+        out.put(hist)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_trainer_reproduces_reference_trajectory():
+def _run_two_ranks(batch, epochs, with_mapping=False, precision="fp32", compress=False):
     world = 2
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, batch, epochs, with_mapping, precision, compress))
+             for r in range(world)]
     for p in procs:
         p.start()
-    hist = out.get(timeout=110)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        hist = out.get(timeout=110)
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:                         # a failed rank must not leave its peer holding the GPU and the port
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return hist
+
+
+def test_two_rank_trainer_reproduces_reference_trajectory():
+    hist = _run_two_ranks(U.cfg(U.load("traj_nb_ber"), "cfg")["batch"], 3)
     d = U.load("traj_nb_ber")
     c = U.cfg(d, "cfg")
     names = list(c["modalities"].keys())
@@ -66,3 +87,29 @@ def test_two_rank_trainer_reproduces_reference_trajectory():
         assert len(tl) == len(ref_t) and len(vl) == 3
         assert float(np.max(np.abs(np.array(tl) - ref_t) / np.abs(ref_t))) < 5e-4, di
         assert float(np.max(np.abs(np.array(vl) - ref_v) / np.abs(ref_v))) < 5e-4, di
+
+
+def _compare(h2, h1, tol):
+    assert set(h2) == set(h1)
+    for k in h1:
+        for a, b in zip(h2[k], h1[k]):
+            assert len(a) == len(b), k
+            assert float(np.max(np.abs(np.array(a) - np.array(b)) / np.abs(np.array(b)))) < tol, (k, a, b)
+
+
+def test_two_rank_trainer_with_an_empty_shard_and_the_mapping_stage():
+    """410 training cells in batches of 409 leave a last global batch of ONE cell: rank 1's shard of it is empty and
+    joins the collectives with zero gradients.  Predictors and the bidirectional mapping stage (also sliced by rank)
+    against the single-process run of the same configuration (itself pinned to the reference by the trajectory tests)."""
+    h2 = _run_two_ranks(409, 2, with_mapping=True)
+    h1 = _train(None, 409, 2, True)
+    _compare(h2, h1, 5e-4)
+
+
+def test_two_rank_trainer_bf16_exchange_buffer():
+    """Precision 'bf16' with GradSync(compress=True): the first-layer weight-gradient kernels write bf16 dW straight
+    into the exchange buffer (the trainer wires it up like bench.py does); losses within the bf16 tolerance of the
+    single-process bf16 run."""
+    h2 = _run_two_ranks(64, 2, precision="bf16", compress=True)
+    h1 = _train(None, 64, 2, False, precision="bf16")
+    _compare(h2, h1, 2e-2)

@@ -303,3 +303,48 @@ def test_vae_modules_golden(S, sparse_in):
                 close(outs[2], d[f"{tag}/rate"], rtol=1e-4, atol=1e-6, what=f"{tag} rate")
                 if c["dist"] == "zinb":
                     close(outs[3], d[f"{tag}/pi"], rtol=1e-4, atol=1e-5, what=f"{tag} pi")
+
+
+def test_inference_heads_golden(S):
+    """The decoder heads predict() runs (scp_ber_prob, scp_relu_softmax_rows) through the modules' no-grad forward and
+    predict_head, over every Bernoulli / raw-count decoder variant of the reference fixtures: all returned tensors in
+    fp32, the kept output [0] also as bf16 (one bf16 rounding of the fp32 result)."""
+    d = U.load("mod_ber")
+    for tag in json.loads(str(d["cases"])):
+        c = U.cfg(d, f"{tag}/cfg")
+        cov = U.opt(d, f"{tag}/cov")
+        dec = S.pkg.Output_Module_Ber(output_dim=64, output_batch_num=0 if cov is None else 3, hidden_layer=[16, 8],
+                                      infer_library_size=c["latlib"], sample_factor=c["sf"], feature_factor=c["ff"])
+        dec = _load(dec, U.sub(d, f"{tag}/sd")).eval()
+        h = torch.tensor(d[f"{tag}/h"]).to(DEV)
+        lib, lat = U.opt(d, f"{tag}/lib"), U.opt(d, f"{tag}/latlib")
+        args = (h, None if cov is None else cov.to(DEV), None if lib is None else lib.to(DEV), None if lat is None else lat.to(DEV))
+        with torch.no_grad():
+            res = dec(*args)
+        close(res[0], d[f"{tag}/out0"], rtol=2e-5, atol=1e-7, what=f"{tag} out0")
+        close(res[1], d[f"{tag}/out1"], rtol=2e-5, atol=1e-7, what=f"{tag} out1")
+        p32 = dec.predict_head(*args)
+        assert torch.equal(p32, res[0])
+        p16 = dec.predict_head(*args, out_dtype=torch.bfloat16)
+        assert p16.dtype == torch.bfloat16 and torch.equal(p16, p32.bfloat16())
+    d = U.load("mod_raw")
+    for tag in json.loads(str(d["cases"])):
+        c = U.cfg(d, f"{tag}/cfg")
+        cov = U.opt(d, f"{tag}/cov")
+        dec = S.pkg.Output_Module_Raw(output_dim=32, output_batch_num=0 if cov is None else 3, hidden_layer=[16, 8],
+                                      infer_library_size=not c["sf"], sample_factor=c["sf"], feature_factor=c["ff"],
+                                      zero_inflated=(c["lik"] == "zinb"), dispersion=c["disp"])
+        dec = _load(dec, U.sub(d, f"{tag}/sd")).eval()
+        h = torch.tensor(d[f"{tag}/h"]).to(DEV)
+        lib, lat = U.opt(d, f"{tag}/lib"), U.opt(d, f"{tag}/latlib")
+        args = (h, None if cov is None else cov.to(DEV), None if lib is None else lib.to(DEV), None if lat is None else lat.to(DEV))
+        with torch.no_grad():
+            scale, theta, rate, pi = dec(*args)
+        close(scale, d[f"{tag}/scale"], rtol=2e-5, atol=1e-8, what=f"{tag} scale")
+        close(theta, d[f"{tag}/theta"], rtol=2e-5, atol=1e-7, what=f"{tag} theta")
+        close(rate, d[f"{tag}/rate"], rtol=2e-5, atol=1e-7, what=f"{tag} rate")
+        if c["lik"] == "zinb":
+            close(pi, d[f"{tag}/pi"], rtol=1e-4, atol=1e-5, what=f"{tag} pi")
+        p32 = dec.predict_head(*args)
+        assert torch.equal(p32, scale)
+        assert torch.equal(dec.predict_head(*args, out_dtype=torch.bfloat16), p32.bfloat16())

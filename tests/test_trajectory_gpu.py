@@ -82,6 +82,14 @@ def test_trajectory_fp32(name):
             g = d["pred/" + k]
             assert v.shape == g.shape
             assert float(np.abs(v - g).max()) < 2e-3 * max(1.0, float(np.abs(g).max())), k
+        # atlas-scale output options: bf16 predictions, top-k per cell
+        p16 = obj.predict(out_dtype=torch.bfloat16)
+        top = obj.predict(topk=5)
+        for k, v in pred.items():
+            assert p16[k].dtype == torch.bfloat16 and torch.equal(p16[k], torch.tensor(v).bfloat16()), k
+            tv, ti = torch.topk(torch.tensor(v), 5, dim=1)
+            assert np.array_equal(top[k]["values"], tv.numpy()), k
+            assert np.array_equal(np.take_along_axis(v, top[k]["indices"], 1), tv.numpy()), k
 
 
 def test_trajectory_bf16():
@@ -139,6 +147,46 @@ def test_vae_trajectory_fp32():
         assert float((v.cpu() - torch.tensor(d["enc_final/" + k])).abs().max()) < 2e-3, k
 
 
+def test_vae_trainer_replays_reference_trajectory():
+    """scVAE_object (the package's epoch loop around train_VAE / eval_VAE, shaped like model.py:727-799) replaying the
+    reference's recorded VAE run: same initial weights, batch order and noise stream -> per-epoch validation
+    (total, reconstruction, KL) within 5e-4 relative and final encoder weights within 2e-3."""
+    d = U.load("traj_vae_nb")
+    c = U.cfg(d, "cfg")
+    rna = synth.make_rna(c["n"], c["g"], seed=c["seed"])
+    obj = S.scVAE_object(distribution="nb", SEED=0, hidden_dim=c["hid"], latent_dim=c["L"], dropout_rate=0, batch_size=c["batch"],
+                         L2_lambda=1e-9, max_epochs=c["epochs"], kl_weight=c["kl_weight"], device=DEV, sample_factor=True,
+                         infer_library_size=False, verbose=False, weight_decay_groups=False)
+    eps_all = torch.tensor(d["eps"]).to(DEV)
+    pos = [0]
+
+    def eps_source(shape, device):
+        n = int(np.prod(shape))
+        e = eps_all[pos[0]:pos[0] + n].reshape(shape)
+        pos[0] += n
+        return e
+    obj.eps_source = eps_source
+    init = ({k: torch.tensor(v) for k, v in U.sub(d, "enc_init", tensor=False).items()},
+            {k: torch.tensor(v) for k, v in U.sub(d, "dec_init", tensor=False).items()})
+    # the package builds the same initial weights from SEED alone (construction order of model.py:620-694)
+    enc0, dec0 = obj.build(c["g"])
+    for k, v in enc0.state_dict().items():
+        assert torch.equal(v, init[0][k]), k
+    for k, v in dec0.state_dict().items():
+        assert torch.equal(v, init[1][k]), k
+    obj.train(rna, rna, batch_replay=U.split_batches(d["rows"], d["batch_sizes"]))
+    assert pos[0] == eps_all.numel()
+    got = np.stack([obj.history["val_loss"], obj.history["val_recon"], obj.history["val_kl"]], 1)
+    assert got.shape == d["eval"].shape
+    assert np.max(np.abs(got - d["eval"]) / np.abs(d["eval"])) < 5e-4, (got, d["eval"])
+    for k, v in obj.last_encoder.state_dict().items():
+        assert float((v.cpu() - torch.tensor(d["enc_final/" + k])).abs().max()) < 2e-3, k
+    assert len(obj.history["train_loss"]) == len(d["batch_sizes"])
+    obj.encoder.eps_source = None                      # the recorded noise stream is used up
+    emb = obj.embeddings(rna)
+    assert emb.shape == (c["n"], c["L"]) and bool(torch.isfinite(emb).all())
+
+
 def test_run_from_anndata_like_object():
     """The reference's top-level workflow `scPair_object(scobj=adata, cov=[...]).run()` (model.py:517-526) on an
     AnnData-like object: data_loader_builder keeps the matrices sparse, the predictors, embeddings and the
@@ -185,27 +233,30 @@ def test_run_with_input_transform():
                         device=torch.device("cuda:0"), input_transform={"Gene Expression": "sqrt"})
 
 
-def test_augment_matches_reference():
+@pytest.mark.parametrize("golden", ["augment", "augment_cov"])
+def test_augment_matches_reference(golden):
     """augment() (model.py:925-1036) from the reference's trained RNA encoder on extra unimodal cells, against the
     four embedding tables and the fine-tuned encoder the reference produced (tests/golden/augment.npz,
     tools/make_golden_augment.py).  Dropout 0 and BatchNorm on make the fine-tuning deterministic: the train-mode
-    batch statistics are the learning signal."""
+    batch statistics are the learning signal.  augment_cov: the paired data carry a one-hot covariate, the unimodal
+    cells none, so their covariate block is all zeros (model.py:936-940)."""
     import json
     import os
     import scipy.sparse as sp
-    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment.npz"))
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", golden + ".npz"))
     c = json.loads(str(d["cfg"]))
+    with_cov = "cov" in d.files
     data = synth.make_paired(c["n"], c["g"], c["p"], seed=c["seed"], p_atac=0.1)
     dicts = []
     for split in ("train", "val", "test"):
         idx = data[split]
-        dicts.append({f"{nm}_{split}_{k}": (mat[idx] if k == "mtx" else None)
+        dicts.append({f"{nm}_{split}_{k}": (mat[idx] if k == "mtx" else (torch.tensor(d["cov"][idx]) if with_cov else None))
                       for nm, mat in (("Gene Expression", data["rna"]), ("Peaks", data["atac"])) for k in ("mtx", "cov")})
-    obj = S.scPair_object(None, cov=None, modalities={"Gene Expression": "nb", "Peaks": "ber"}, SEED=0,
-                          hidden_layer=c["hidden"], dropout_rate=0.0, batchnorm=True, layernorm=True,
+    obj = S.scPair_object(None, cov=(["labels"] if with_cov else None), modalities={"Gene Expression": "nb", "Peaks": "ber"},
+                          SEED=0, hidden_layer=c["hidden"], dropout_rate=0.0, batchnorm=True, layernorm=True,
                           batch_size=c["batch"], max_epochs=c["aug_epochs"], device=DEV, save_model=False, verbose=False)
     obj.set_data(*dicts)
-    enc, _, _ = obj._build_predictor("Gene Expression", "Peaks", c["g"], c["p"], 0)
+    enc, _, _ = obj._build_predictor("Gene Expression", "Peaks", c["g"], c["p"], 4 if with_cov else 0)
     sd = {k[len("enc_trained/"):]: torch.tensor(d[k]) for k in d.files if k.startswith("enc_trained/")}
     enc.load_state_dict(sd)
     obj.encoder_dict = {"Gene Expression to Peaks": enc.eval()}
