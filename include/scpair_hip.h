@@ -123,6 +123,32 @@ int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, long ldx, con
                    float* dgamma, float* dbeta, float* dbias /* each [H], nullable */, float* partials_ws,
                    void* stream);
 
+/* ---- encoder tail: what Input_Module (model.py:60-143) does between the wide first-layer product and its output,
+ *      i.e. the rest of a two-layer FCNN (utils.py:54-64: + bias, LayerNorm, LeakyReLU/ReLU, Dropout; Linear(H1, H2),
+ *      LayerNorm, activation, Dropout) and the Linear behind it (extra_linear_rep model.py:83-84, or the library head
+ *      Linear(H2, 1) model.py:92; N3 = 0: none), as one forward call and one backward call.  Exact fp32.
+ *      Needs H1 % 4 == 0, H1 <= 1024, H2 <= 64, N3 <= 64, LayerNorm on both layers, 16-byte aligned H1-wide tensors.
+ *      fwd: slabs [nslab][B][H1] = split-K partials of x W1^T (scp_spmm_fwd*, scp_gemm_nt); out [B][N3] (N3 = 0: [B][H2]);
+ *           xhat1 [B][H1], rstd1 [B], xhat2 [B][H2], rstd2 [B] are written for the backward (all null: inference).
+ *      bwd: dOut [B][N3 or H2] -> dY1 [B][ldy] (gradient of the first-layer product: feed scp_spmm_dw* with it) and the
+ *           gradients of every tensor of the tail (each nullable); ws: scp_enc_tail_ws_floats(B, H1, H2, N3) floats ---- */
+typedef struct {
+  int B, H1, H2, N3;
+  const float *b1, *g1, *be1;          /* first layer: bias (nullable), LayerNorm weight / bias   [H1] */
+  const float *W2, *b2, *g2, *be2;     /* second layer: weight [H2][H1], bias, LayerNorm weight / bias [H2] */
+  const float *W3, *b3;                /* final Linear: weight [N3][H2], bias [N3] */
+  float eps1, eps2, slope, p1, p2;     /* LayerNorm eps, activation slope, dropout probabilities */
+  uint64_t seed1, seed2;               /* dropout seeds of the two layers */
+  const uint64_t* seed_dev;            /* nullable: device word added to both seeds (scp_step_state_set) */
+  float *xhat1, *rstd1, *xhat2, *rstd2;
+} ScpEncTail;
+int scp_enc_tail_fwd(const ScpEncTail* m, const float* slabs, long slab_stride, int nslab, float* out, long ldo,
+                     void* stream);
+long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3);
+int scp_enc_tail_bwd(const ScpEncTail* m, const float* dOut, long lddo, float* dY1, long ldy, float* ws, float* dg1,
+                     float* dbe1, float* db1, float* dW2, float* dg2, float* dbe2, float* db2, float* dW3, float* db3,
+                     void* stream);
+
 /* ---- Bernoulli decoder + BCE, fused forward(+backward): Output_Module_Ber.forward (model.py:164-190)
  *      + binarized_loss (loss.py:36-41, BCELoss log clamp -100, NaN labels masked) ---- */
 int scp_dec_chunks(int F);

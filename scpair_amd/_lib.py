@@ -29,6 +29,14 @@ class AdamTensor(C.Structure):
                 ("p_bf16", P), ("cols", L), ("ld_bf16", L), ("g_bf16", L), ("bc_dev", P)]
 
 
+class EncTail(C.Structure):
+    _fields_ = [("B", I), ("H1", I), ("H2", I), ("N3", I),
+                ("b1", P), ("g1", P), ("be1", P), ("W2", P), ("b2", P), ("g2", P), ("be2", P), ("W3", P), ("b3", P),
+                ("eps1", F), ("eps2", F), ("slope", F), ("p1", F), ("p2", F),
+                ("seed1", U64), ("seed2", U64), ("seed_dev", P),
+                ("xhat1", P), ("rstd1", P), ("xhat2", P), ("rstd2", P)]
+
+
 _SIGS = {
     "scp_last_error": (C.c_char_p, []),
     "scp_version": (I, []),
@@ -58,6 +66,9 @@ _SIGS = {
     "scp_ln_act_fwd": (I, [P, L, L, I, P, P, P, I, I, F, F, F, U64, P, P, L, P, P, L, P]),
     "scp_ln_act_bwd_grid": (I, [I]),
     "scp_ln_act_bwd": (I, [P, L, P, L, P, P, P, I, I, F, F, U64, P, P, L, P, P, P, P, P]),
+    "scp_enc_tail_fwd": (I, [C.POINTER(EncTail), P, L, I, P, L, P]),
+    "scp_enc_tail_ws_floats": (L, [I, I, I, I]),
+    "scp_enc_tail_bwd": (I, [C.POINTER(EncTail), P, L, P, L, P, P, P, P, P, P, P, P, P, P, P]),
     "scp_dec_chunks": (I, [I]),
     "scp_dec_kp": (I, [I]),
     "scp_dec_ws_floats": (L, [I, I, I]),

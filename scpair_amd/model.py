@@ -22,8 +22,8 @@ import torch.nn.functional as F
 from . import ops
 from .loss import binarized_loss, raw_loss, scaled_loss
 from .sparse import BatchTiles, DeviceCSR
-from .utils import (FCNN, HipLinear, add_weight_decay, eval_net, evaluating_mode, init_weights, set_seed,
-                    train_net, training_mode)
+from .utils import (FCNN, HipLinear, add_weight_decay, encoder_branch, eval_net, evaluating_mode, init_weights,
+                    set_seed, train_net, training_mode)
 
 
 def clear_gpu_memory():
@@ -84,11 +84,10 @@ class Input_Module(nn.Module):
                                             HipLinear(hidden_layer[-1], 1, bias=True))
 
     def forward(self, input, input_batch):
-        latent_rep = self.hidden_rep(input, input_batch)
-        if self.add_linear_layer is True:
-            latent_rep = self.extra_linear_rep(latent_rep)
+        latent_rep = encoder_branch(self.hidden_rep, self.extra_linear_rep if self.add_linear_layer is True else None,
+                                    input, input_batch)
         if self.infer_library_size == True:  # noqa: E712
-            latent_lib = self.hidden_lib[1](self.hidden_lib[0](input, input_batch))
+            latent_lib = encoder_branch(self.hidden_lib[0], self.hidden_lib[1], input, input_batch)
         else:
             latent_lib = None
         return latent_rep, latent_lib

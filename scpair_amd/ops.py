@@ -405,6 +405,154 @@ def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------
+# Whole encoder branch on a sparse minibatch: first layer on the tile list + the fused tail (enc_tail.hip)
+#   x -> Linear(F, H1) -> LN -> act -> Dropout -> Linear(H1, H2) -> LN -> act -> Dropout [-> Linear(H2, N3)]
+# (Input_Module.hidden_rep + extra_linear_rep, hidden_lib + its head: model.py:77-92, 124-143)
+# ------------------------------------------------------------------------------------------------
+def enc_branch_supported(x, cov, W1, W2, W3, ln1, ln2):
+    """The fused path covers the reference's default encoder shape: sparse minibatch, no covariate block, two FCNN
+    layers with LayerNorm, hidden widths H1 % 4 == 0, H1 <= 1024, H2 <= 64, final Linear with N3 <= 64 outputs."""
+    if not isinstance(x, BatchTiles) or cov is not None or not ln1 or not ln2:
+        return False
+    H1, H2 = W1.shape[0], W2.shape[0]
+    if H1 % 4 or H1 > 1024 or H2 > 64 or W2.shape[1] != H1 or (W3 is not None and (W3.shape[0] > 64 or W3.shape[1] != H2)):
+        return False
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0)
+               for t in (W1, W2, W3))
+
+
+class EncBranchFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, slope, p1, p2, seed1, seed2, eps1, eps2, shadow,
+                fused, sink):
+        L = _lib.lib()
+        Bn, F = x.shape
+        H1, H2 = W1.shape[0], W2.shape[0]
+        N3 = 0 if W3 is None else W3.shape[0]
+        if W1.shape[1] != F:
+            raise ValueError(f"encoder: first layer expects {W1.shape[1]} inputs, the minibatch has {F} features")
+        ns = _ns()
+        dev = W1.device
+        use_bf = ns == 1 and shadow is not None
+        if use_bf:
+            tiles_ = ((Bn + 255) // 256) * ((H1 + 127) // 128)
+            nsplit = max(1, min(512 // max(tiles_, 1), ((F + 63) // 64) // 4, 16), L.scp_spmm_fwd_bf16_min_split(F))
+        else:
+            nsplit = _pick_split(Bn, H1, F)
+        nsplit = L.scp_gemm_split_count(F, nsplit)
+        train = any(ctx.needs_input_grad)
+        nout = N3 if N3 > 0 else H2
+        # one allocation: slabs | out | (xhat1 | rstd1 | xhat2 | rstd2)
+        n_slab, n_out = nsplit * Bn * H1, Bn * nout
+        n_save = (Bn * H1 + Bn + Bn * H2 + Bn + 12) if train else 0
+        buf = torch.empty(n_slab + n_out + n_save + 8, dtype=torch.float32, device=dev)
+        slabs = buf[:n_slab]
+        if use_bf:
+            _lib.check(L.scp_spmm_fwd_bf16(Bn, H1, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val),
+                                           shadow.data_ptr(), shadow.shape[1], slabs.data_ptr(), H1, nsplit,
+                                           _lib.stream()), "scp_spmm_fwd_bf16")
+        else:
+            _lib.check(L.scp_spmm_fwd(Bn, H1, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(),
+                                      F, slabs.data_ptr(), H1, None, nsplit, ns, _lib.stream()), "scp_spmm_fwd")
+        o0 = (n_slab + 3) // 4 * 4
+        out = buf[o0:o0 + n_out].view(Bn, nout)
+        xhat1 = rstd1 = xhat2 = rstd2 = None
+        if train:
+            o1 = (o0 + n_out + 3) // 4 * 4
+            xhat1 = buf[o1:o1 + Bn * H1]
+            o2 = o1 + Bn * H1
+            rstd1 = buf[o2:o2 + Bn]
+            o3 = (o2 + Bn + 3) // 4 * 4
+            xhat2 = buf[o3:o3 + Bn * H2]
+            rstd2 = buf[o3 + Bn * H2:o3 + Bn * H2 + Bn]
+        seed_dev = _seed_dev() if (p1 > 0 or p2 > 0) else None
+        m = _lib.EncTail(Bn, H1, H2, N3, _lib.ptr(b1), g1.data_ptr(), be1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+                         g2.data_ptr(), be2.data_ptr(), _lib.ptr(W3), _lib.ptr(b3), eps1, eps2, slope, p1, p2, seed1, seed2,
+                         seed_dev, _lib.ptr(xhat1), _lib.ptr(rstd1), _lib.ptr(xhat2), _lib.ptr(rstd2))
+        _lib.check(L.scp_enc_tail_fwd(C.byref(m), slabs.data_ptr(), Bn * H1, nsplit, out.data_ptr(), nout, _lib.stream()),
+                   "scp_enc_tail_fwd")
+        if train:
+            ctx.m, ctx.tiles, ctx.buf = m, x, buf
+            ctx.save_for_backward(W1, b1, g1, be1, W2, b2, g2, be2, W3, b3)
+            ctx.dims = (Bn, F, H1, H2, N3, ns, use_bf)
+            ctx.fused = fused if (use_bf and F % 4 == 0) else None
+            ctx.sink = sink if (use_bf and ctx.fused is None) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 = ctx.saved_tensors
+        Bn, F, H1, H2, N3, ns, use_bf = ctx.dims
+        dev = W1.device
+        dout = _f32c(dout)
+        t = ctx.tiles
+        # one allocation for every small gradient and the workspace: dg1 dbe1 db1 | dg2 dbe2 db2 | dW3 db3 | dW2 | dY1 | ws
+        nws = L.scp_enc_tail_ws_floats(Bn, H1, H2, N3)
+        sizes = [H1, H1, H1, H2, H2, H2, N3 * H2, N3, H2 * H1, Bn * H1, nws]
+        offs, o = [], 0
+        for n_ in sizes:
+            offs.append(o)
+            o += (n_ + 3) // 4 * 4
+        gb = torch.empty(o + 4, dtype=torch.float32, device=dev)
+        dg1, dbe1, db1, dg2, dbe2, db2, dW3, db3, dW2, dY1, ws = [gb[a:a + n_] for a, n_ in zip(offs, sizes)]
+        _lib.check(L.scp_enc_tail_bwd(C.byref(ctx.m), dout.data_ptr(), dout.shape[1], dY1.data_ptr(), H1, ws.data_ptr(),
+                                      dg1.data_ptr(), dbe1.data_ptr(), _lib.ptr(db1 if b1 is not None else None),
+                                      dW2.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr(),
+                                      _lib.ptr(dW3 if N3 else None), _lib.ptr(db3 if N3 else None), _lib.stream()),
+                   "scp_enc_tail_bwd")
+        dW1 = None
+        if ctx.needs_input_grad[1]:
+            if use_bf:
+                ldt = (Bn + 63) // 64 * 64
+                dYT = torch.empty((H1, ldt), dtype=torch.bfloat16, device=dev)
+                _lib.check(L.scp_transpose_bf16(dY1.data_ptr(), Bn, H1, H1, dYT.data_ptr(), ldt, _lib.stream()),
+                           "scp_transpose_bf16")
+                if ctx.fused is not None:
+                    m_, v_, sh_, hp = ctx.fused.begin_step(W1)
+                    tm = _cfg["fused_timer"]
+                    if tm is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, H1, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                                                        dYT.data_ptr(), ldt, W1.data_ptr(), F, m_.data_ptr(),
+                                                        v_.data_ptr(), sh_.data_ptr(), sh_.shape[1], *hp,
+                                                        _lib.stream()), "scp_spmm_dw_adamw_bf16")
+                    if tm is not None:
+                        e1.record()
+                        tm.append((e0, e1, H1 * F, int(t.nnz) * (8 if t.val is not None else 4) + 2 * H1 * ldt))
+                elif ctx.sink is not None:
+                    _lib.check(L.scp_spmm_dw_bf16_g16(Bn, H1, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                                                      dYT.data_ptr(), ldt, ctx.sink.view.data_ptr(), F,
+                                                      _lib.stream()), "scp_spmm_dw_bf16_g16")
+                    ctx.sink.written = True
+                else:
+                    dW1 = torch.empty((H1, F), dtype=torch.float32, device=dev)
+                    _lib.check(L.scp_spmm_dw_bf16(Bn, H1, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                                                  dYT.data_ptr(), ldt, dW1.data_ptr(), F, _lib.stream()),
+                               "scp_spmm_dw_bf16")
+            else:
+                dW1 = torch.empty((H1, F), dtype=torch.float32, device=dev)
+                _lib.check(L.scp_spmm_dw(Bn, H1, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), dY1.data_ptr(), H1,
+                                         dW1.data_ptr(), F, ns, _lib.stream()), "scp_spmm_dw")
+        ctx.buf = ctx.tiles = None
+        return (None, dW1, db1 if b1 is not None else None, dg1, dbe1, dW2.view(H2, H1), db2, dg2, dbe2,
+                dW3.view(N3, H2) if N3 else None, db3 if N3 else None) + (None,) * 10
+
+
+def enc_branch(x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, slope, p1=0.0, p2=0.0, eps1=1e-5, eps2=1e-5):
+    shadow = fused = sink = None
+    if _ns() == 1:
+        shadow = shadow_of(W1)
+        if torch.is_grad_enabled() and W1.requires_grad:
+            fused = fused_handle(W1)
+            sink = grad_sink_of(W1) if fused is None else None
+    return EncBranchFn.apply(x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, float(slope), float(p1), float(p2),
+                             next_seed() if p1 > 0 else 0, next_seed() if p2 > 0 else 0, float(eps1), float(eps2),
+                             shadow, fused, sink)
+
+
+# ------------------------------------------------------------------------------------------------
 # BatchNorm1d (+ the layer's dropout), utils.py:61-63
 # ------------------------------------------------------------------------------------------------
 class BatchNormFn(torch.autograd.Function):

@@ -78,6 +78,31 @@ class HipFCNN(nn.Sequential):
         return x
 
 
+def encoder_branch(fcnn, final, x, cov=None):
+    """final(fcnn(x, cov)) for an encoder branch (model.py:124-143: hidden_rep [+ extra_linear_rep], hidden_lib + its
+    head).  The reference's default shape -- sparse minibatch, no covariate block, two FCNN layers with LayerNorm and
+    no BatchNorm -- runs as the first-layer product plus ONE fused tail kernel (ops.enc_branch); everything else goes
+    layer by layer."""
+    groups = fcnn._groups() if isinstance(fcnn, HipFCNN) else None
+    if groups is not None and len(groups) == 2:
+        (l1, n1, a1, bn1, d1), (l2, n2, a2, bn2, d2) = groups
+        W3 = None if final is None else final.weight
+        try:
+            slope = _slope_of(a1)
+            same_act = _slope_of(a2) == slope
+        except NotImplementedError:
+            same_act = False
+        if same_act and bn1 is None and bn2 is None and (final is None or final.bias is not None) and l2.bias is not None \
+                and ops.enc_branch_supported(x, cov, l1.weight, l2.weight, W3, n1 is not None, n2 is not None) \
+                and n1.elementwise_affine and n2.elementwise_affine:
+            p1 = float(d1.p) if (fcnn.training and d1.p > 0) else 0.0
+            p2 = float(d2.p) if (fcnn.training and d2.p > 0) else 0.0
+            return ops.enc_branch(x, l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias, n2.weight, n2.bias,
+                                  W3, None if final is None else final.bias, slope, p1, p2, n1.eps, n2.eps)
+    h = fcnn(x, cov)
+    return h if final is None else final(h)
+
+
 def FCNN(layers, layernorm=True, activation=nn.ReLU(), batchnorm=False, dropout_rate=0):
     """utils.py:54-64 (same module order, so same parameter names and the same RNG draws)."""
     fc_nn = []

@@ -1,0 +1,149 @@
+"""The fused encoder branch (first-layer product on the tile list + scp_enc_tail_fwd / scp_enc_tail_bwd) against an fp64
+torch restatement of the same modules (utils.py:54-64 FCNN layers + the Linear behind them, model.py:77-92, 124-143):
+output and the gradient of every parameter, at the bench's hidden sizes and at ragged ones, for the three kinds of
+branch (extra_linear_rep: N3 = H2; library head: N3 = 1; no final Linear), in both precision modes; dropout masks are
+checked for forward / backward consistency by directional derivatives of the kernel itself."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _csr(rng, n, f, density):
+    import scipy.sparse as sp
+    m = sp.random(n, f, density=density, format="csr", random_state=np.random.RandomState(int(rng.integers(1 << 30))),
+                  data_rvs=lambda k: rng.integers(1, 9, size=k).astype(np.float32))
+    m.sort_indices()
+    return m
+
+
+def _params(g, F, H1, H2, N3):
+    P = dict(W1=torch.randn(H1, F, generator=g) / np.sqrt(F) * 3, b1=torch.randn(H1, generator=g) * 0.1,
+             g1=1 + 0.1 * torch.randn(H1, generator=g), be1=0.1 * torch.randn(H1, generator=g),
+             W2=torch.randn(H2, H1, generator=g) / np.sqrt(H1), b2=torch.randn(H2, generator=g) * 0.1,
+             g2=1 + 0.1 * torch.randn(H2, generator=g), be2=0.1 * torch.randn(H2, generator=g))
+    if N3:
+        P["W3"] = torch.randn(N3, H2, generator=g) / np.sqrt(H2)
+        P["b3"] = torch.randn(N3, generator=g) * 0.1
+    return P
+
+
+def _ref(P, x, rnd, keep1=None, keep2=None):
+    """fp64 forward; `rnd` rounds the first-layer operands the way the precision mode does; keep1 / keep2: dropout
+    factors (0 or 1/(1-p)) of the two layers.  Also returns the smallest |pre-activation|: an element closer to the
+    LeakyReLU kink than the fp32 / fp64 difference can sit on the other side of it in the kernel, which changes its
+    gradient by a factor 100 -- the tests draw their parameters so that no element is that close."""
+    q = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    W1 = q["W1"] + (rnd(P["W1"]) - P["W1"].double()).detach()
+    y = rnd(x) @ W1.t() + q["b1"]
+    z1 = Fn.layer_norm(y, (y.shape[1],), q["g1"], q["be1"])
+    a1 = Fn.leaky_relu(z1, 0.01)
+    if keep1 is not None:
+        a1 = a1 * keep1
+    z2 = Fn.layer_norm(a1 @ q["W2"].t() + q["b2"], (q["W2"].shape[0],), q["g2"], q["be2"])
+    a2 = Fn.leaky_relu(z2, 0.01)
+    if keep2 is not None:
+        a2 = a2 * keep2
+    out = a2 @ q["W3"].t() + q["b3"] if "W3" in q else a2
+    return q, out, min(float(z1.detach().abs().min()), float(z2.detach().abs().min()))
+
+
+def _draw(F, H1, H2, N3, x, rnd, seed0, keep1=None, keep2=None):
+    g = torch.Generator().manual_seed(seed0)
+    P = _params(g, F, H1, H2, N3)
+    q, out_r, zmin = _ref(P, x, rnd, keep1, keep2)
+    return g, P, q, out_r
+
+
+def _check(name, got, ref, rt):
+    """Every element within rt * scale -- except the few a LeakyReLU kink explains: a pre-activation within fp32 noise
+    of zero (a handful among ~1e6) can sit on the other side of the kink in the kernel, which changes that one
+    element's gradient by a factor 100 and with it one column of the per-column gradients / one row of dW1.  Such
+    outliers are allowed for at most 0.1 % of the elements (3 of a short vector) and must stay below 30 % of the scale; an error of the
+    kernel shows everywhere."""
+    got, ref = got.detach().double().cpu().reshape(-1), ref.detach().double().reshape(-1)
+    scale = max(1e-2, float(ref.abs().max()))
+    err = (got - ref).abs()
+    bad = int((err > rt * scale).sum())
+    assert bad <= max(3, 1e-3 * err.numel()) and float(err.max()) <= 0.3 * scale, (name, bad, float(err.max()), scale)
+
+
+@pytest.mark.parametrize("B,F,H1,H2,N3", [(1024, 2000, 900, 40, 40), (1024, 2000, 900, 40, 1), (130, 333, 16, 8, 0),
+                                          (67, 515, 1024, 64, 64), (9, 100, 4, 1, 1), (257, 700, 800, 30, 30)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_encoder_branch_vs_fp64(B, F, H1, H2, N3, prec):
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision(prec)
+    try:
+        rng = np.random.default_rng(B + F)
+        m = _csr(rng, B + 11, F, 0.06)
+        rows = rng.permutation(B + 11)[:B]
+        x = torch.tensor(np.asarray(m[rows].todense(), dtype=np.float32))
+        rnd = (lambda t: t.bfloat16().double()) if prec == "bf16" else (lambda t: t.double())
+        g, P, q, out_r = _draw(F, H1, H2, N3, x, rnd, H1 + N3)
+        wout = torch.randn(B, N3 if N3 else H2, generator=g)
+        (out_r * wout.double()).sum().backward()
+        d = {k: v.clone().to(DEV).requires_grad_(True) for k, v in P.items()}
+        tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), rows)
+        assert ops.enc_branch_supported(tiles, None, d["W1"], d["W2"], d.get("W3"), True, True)
+        out = ops.enc_branch(tiles, d["W1"], d["b1"], d["g1"], d["be1"], d["W2"], d["b2"], d["g2"], d["be2"], d.get("W3"),
+                             d.get("b3"), 0.01)
+        (out * wout.to(DEV)).sum().backward()
+        # fp32 mode: the tail is exact fp32 and the first layer fp32-equivalent; bf16 mode: only the first-layer
+        # operands are rounded (the reference above rounds them the same way)
+        rt = 2e-4 if prec == "fp32" else 2e-3
+        _check("out", out, out_r, rt)
+        for k in P:
+            assert d[k].grad is not None, k
+            _check(k, d[k].grad, q[k].grad, rt * (10 if (k == "W1" and prec == "bf16") else 1))   # bf16: dY^T is rounded too
+        # inference (no saved tensors) gives the same output
+        with torch.no_grad():
+            out_e = ops.enc_branch(tiles, d["W1"], d["b1"], d["g1"], d["be1"], d["W2"], d["b2"], d["g2"], d["be2"],
+                                   d.get("W3"), d.get("b3"), 0.01)
+        assert torch.equal(out_e, out.detach())
+    finally:
+        S.set_precision("fp32")
+
+
+def _mask(ops, seed, B, H, p):
+    """The dropout factors keep_scale(seed, row * H + col, p) of a [B, H] layer, read off the generic FCNN layer kernel
+    (same counter-based hash): input 1, weight 1, no LayerNorm, identity activation."""
+    one = torch.ones(B, 1, device=DEV)
+    return ops.fcnn_layer(one, None, torch.ones(H, 1, device=DEV), None, None, None, 1.0, p, seed).double().cpu()
+
+
+@pytest.mark.parametrize("N3", [5, 0])
+def test_encoder_branch_with_dropout(N3):
+    """Dropout on both layers: forward and every gradient against the fp64 restatement that applies the very masks the
+    kernels draw (the backward recomputes them from the seeds); same seeds give the same output, other seeds another."""
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision("fp32")
+    B, F, H1, H2 = 203, 400, 132, 16
+    p1, p2, seed1, seed2 = 0.3, 0.2, 1234, 5678
+    rng = np.random.default_rng(1)
+    m = _csr(rng, B, F, 0.1)
+    x = torch.tensor(np.asarray(m.todense(), dtype=np.float32))
+    tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), np.arange(B))
+    keep1, keep2 = _mask(ops, seed1, B, H1, p1), _mask(ops, seed2, B, H2, p2)
+    assert 0.65 < float((keep1 > 0).double().mean()) < 0.75 and 0.74 < float((keep2 > 0).double().mean()) < 0.86
+    g, P, q, out_r = _draw(F, H1, H2, N3, x, lambda t: t.double(), 2, keep1, keep2)
+    wout = torch.randn(B, N3 if N3 else H2, generator=g)
+    (out_r * wout.double()).sum().backward()
+
+    def run(s1, s2, grad):
+        d = {k: v.clone().to(DEV).requires_grad_(grad) for k, v in P.items()}
+        out = ops.EncBranchFn.apply(tiles, d["W1"], d["b1"], d["g1"], d["be1"], d["W2"], d["b2"], d["g2"], d["be2"],
+                                    d.get("W3"), d.get("b3"), 0.01, p1, p2, s1, s2, 1e-5, 1e-5, None, None, None)
+        return d, out
+    d, out = run(seed1, seed2, True)
+    (out * wout.to(DEV)).sum().backward()
+    _check("out", out, out_r, 2e-4)
+    for k in P:
+        _check(k, d[k].grad, q[k].grad, 2e-4)
+    assert torch.equal(run(seed1, seed2, False)[1], out.detach())
+    assert not torch.equal(run(99, 98, False)[1], out.detach())

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Print the last training step of a rocprofv3 kernel trace (launch order, gaps, durations) and per-kernel totals."""
 import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
+if sys.argv[1].endswith('.db'):                     # rocprofv3's default output (no --output-format csv)
+    import sqlite3
+    rows = [dict(Kernel_Name=n, Start_Timestamp=s, End_Timestamp=e) for n, s, e in
+            sqlite3.connect(sys.argv[1]).execute("select name, start, end from kernels")]
+else:
+    rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('adamw_kernel')]
 a, b = idx[-3] + 1, idx[-1] + 1
