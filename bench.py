@@ -182,7 +182,7 @@ def main():
         loss = _predictor_loss(tx, ty, lib, D.enc, D.dec, D.dist, False, None, None)
         t1_ = pc()
         D.opt.zero_grad()
-        loss.backward()
+        S.ops.backward_root(loss)
         host_t["fwd"] += t1_ - t0_
         host_t["bwd"] += pc() - t1_
         params = [p for g in D.opt.param_groups for p in g["params"] if p.grad is not None]

@@ -126,12 +126,17 @@ int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, long ldx, con
 /* ---- encoder tail: what Input_Module (model.py:60-143) does between the wide first-layer product and its output,
  *      i.e. the rest of a two-layer FCNN (utils.py:54-64: + bias, LayerNorm, LeakyReLU/ReLU, Dropout; Linear(H1, H2),
  *      LayerNorm, activation, Dropout) and the Linear behind it (extra_linear_rep model.py:83-84, or the library head
- *      Linear(H2, 1) model.py:92; N3 = 0: none), as one forward call and one backward call.  Exact fp32.
- *      Needs H1 % 4 == 0, H1 <= 1024, H2 <= 64, N3 <= 64, LayerNorm on both layers, 16-byte aligned H1-wide tensors.
- *      fwd: slabs [nslab][B][H1] = split-K partials of x W1^T (scp_spmm_fwd*, scp_gemm_nt); out [B][N3] (N3 = 0: [B][H2]);
- *           xhat1 [B][H1], rstd1 [B], xhat2 [B][H2], rstd2 [B] are written for the backward (all null: inference).
- *      bwd: dOut [B][N3 or H2] -> dY1 [B][ldy] (gradient of the first-layer product: feed scp_spmm_dw* with it) and the
- *           gradients of every tensor of the tail (each nullable); ws: scp_enc_tail_ws_floats(B, H1, H2, N3) floats ---- */
+ *      Linear(H2, 1) model.py:92; N3 = 0: none), as one forward call and one backward call for up to
+ *      SCP_ENC_TAIL_MAX_BRANCHES branches of one encoder (hidden_rep and hidden_lib, model.py:124-143).  Exact fp32.
+ *      Needs H1 % 4 == 0, H1 <= 1024, H2 <= 64, N3 <= 64, LayerNorm on both layers, 16-byte aligned H1-wide tensors;
+ *      the branches of a call share B.
+ *      fwd: slabs [nslab][B][ld_slab] = split-K partials of x W1^T (scp_spmm_fwd*, scp_gemm_nt; a branch may be a
+ *           column block of a wider product: ld_slab >= H1); out [B][N3] (N3 = 0: [B][H2]); xhat1 [B][H1], rstd1 [B],
+ *           xhat2 [B][H2], rstd2 [B] are written for the backward (all null: inference).
+ *      bwd: dOut [B][N3 or H2] -> the gradient of the first-layer product as fp32 dY1 [B][ldy] and / or as the
+ *           transposed bf16 dYT [H1][ldt] scp_spmm_dw_*bf16 takes (ldt >= B rounded up to 64; either may be null), and
+ *           the gradients of every tensor of the tail (each nullable); ws: scp_enc_tail_ws_floats(B, H1, H2, N3) floats. ---- */
+#define SCP_ENC_TAIL_MAX_BRANCHES 4
 typedef struct {
   int B, H1, H2, N3;
   const float *b1, *g1, *be1;          /* first layer: bias (nullable), LayerNorm weight / bias   [H1] */
@@ -141,13 +146,19 @@ typedef struct {
   uint64_t seed1, seed2;               /* dropout seeds of the two layers */
   const uint64_t* seed_dev;            /* nullable: device word added to both seeds (scp_step_state_set) */
   float *xhat1, *rstd1, *xhat2, *rstd2;
+  /* forward */
+  const float* slabs; long slab_stride, ld_slab; int nslab;
+  float* out; long ldo;
+  /* backward */
+  const float* dOut; long lddo;
+  float* dY1; long ldy;
+  void* dYT; long ldt;
+  float* ws;
+  float *dg1, *dbe1, *db1, *dW2, *dg2, *dbe2, *db2, *dW3, *db3;
 } ScpEncTail;
-int scp_enc_tail_fwd(const ScpEncTail* m, const float* slabs, long slab_stride, int nslab, float* out, long ldo,
-                     void* stream);
+int scp_enc_tail_fwd(const ScpEncTail* branches, int nbranch, void* stream);
 long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3);
-int scp_enc_tail_bwd(const ScpEncTail* m, const float* dOut, long lddo, float* dY1, long ldy, float* ws, float* dg1,
-                     float* dbe1, float* db1, float* dW2, float* dg2, float* dbe2, float* db2, float* dW3, float* db3,
-                     void* stream);
+int scp_enc_tail_bwd(const ScpEncTail* branches, int nbranch, void* stream);
 
 /* ---- Bernoulli decoder + BCE, fused forward(+backward): Output_Module_Ber.forward (model.py:164-190)
  *      + binarized_loss (loss.py:36-41, BCELoss log clamp -100, NaN labels masked) ---- */

@@ -34,7 +34,11 @@ class EncTail(C.Structure):
                 ("b1", P), ("g1", P), ("be1", P), ("W2", P), ("b2", P), ("g2", P), ("be2", P), ("W3", P), ("b3", P),
                 ("eps1", F), ("eps2", F), ("slope", F), ("p1", F), ("p2", F),
                 ("seed1", U64), ("seed2", U64), ("seed_dev", P),
-                ("xhat1", P), ("rstd1", P), ("xhat2", P), ("rstd2", P)]
+                ("xhat1", P), ("rstd1", P), ("xhat2", P), ("rstd2", P),
+                ("slabs", P), ("slab_stride", L), ("ld_slab", L), ("nslab", I), ("out", P), ("ldo", L),
+                ("dOut", P), ("lddo", L), ("dY1", P), ("ldy", L), ("dYT", P), ("ldt", L), ("ws", P),
+                ("dg1", P), ("dbe1", P), ("db1", P), ("dW2", P), ("dg2", P), ("dbe2", P), ("db2", P), ("dW3", P),
+                ("db3", P)]
 
 
 _SIGS = {
@@ -66,9 +70,9 @@ _SIGS = {
     "scp_ln_act_fwd": (I, [P, L, L, I, P, P, P, I, I, F, F, F, U64, P, P, L, P, P, L, P]),
     "scp_ln_act_bwd_grid": (I, [I]),
     "scp_ln_act_bwd": (I, [P, L, P, L, P, P, P, I, I, F, F, U64, P, P, L, P, P, P, P, P]),
-    "scp_enc_tail_fwd": (I, [C.POINTER(EncTail), P, L, I, P, L, P]),
+    "scp_enc_tail_fwd": (I, [C.POINTER(EncTail), I, P]),
     "scp_enc_tail_ws_floats": (L, [I, I, I, I]),
-    "scp_enc_tail_bwd": (I, [C.POINTER(EncTail), P, L, P, L, P, P, P, P, P, P, P, P, P, P, P]),
+    "scp_enc_tail_bwd": (I, [C.POINTER(EncTail), I, P]),
     "scp_dec_chunks": (I, [I]),
     "scp_dec_kp": (I, [I]),
     "scp_dec_ws_floats": (L, [I, I, I]),

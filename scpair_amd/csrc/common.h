@@ -106,6 +106,21 @@ __device__ __forceinline__ void adamw_update(const AdamHyper& h, float& p, float
 }
 
 // ---- wave / block reductions -------------------------------------------------------------
+// Cross-lane moves on the vector ALU (no LDS round trip like __shfl_xor's ds_bpermute): DPP within a row of 16 lanes,
+// gfx950's permlane swaps across rows.  CTRL: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1]
+// (lane ^ 2), 0x120 + n = row_ror n.  All lanes of the wave must be active.
+template <int CTRL> __device__ __forceinline__ float dppf(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float xor16_sum(float v) {      // v[lane] + v[lane ^ 16]
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {      // v[lane] + v[lane ^ 32]
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -200,7 +215,11 @@ __device__ __forceinline__ float lgamma_terms(float x, float theta) {
 
 // math flavour: accurate libm in the fp32-equivalent mode (NS=3), hardware exp/log/rcp in bf16 mode (NS=1)
 template <bool FAST> __device__ __forceinline__ float exp_(float x) { return FAST ? __expf(x) : expf(x); }
-template <bool FAST> __device__ __forceinline__ float log_(float x) { return FAST ? __logf(x) : logf(x); }
+// FAST: the bare v_log_f32 (log2, ~1 ulp) times ln 2 -- two instructions; __logf() expands to twelve (denormal
+// rescaling and an extended-precision product).  Denormal arguments flush to log(0) = -inf, which every caller clamps.
+template <bool FAST> __device__ __forceinline__ float log_(float x) {
+  return FAST ? __builtin_amdgcn_logf(x) * 0.69314718f : logf(x);
+}
 template <bool FAST> __device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 template <bool FAST> __device__ __forceinline__ float sigm_(float x) { return div_<FAST>(1.f, 1.f + exp_<FAST>(-x)); }
 

@@ -1,23 +1,32 @@
 // Encoder "tail": everything of Input_Module (model.py:60-143) between the wide first-layer product and the latent
-// output, in one forward kernel and three backward kernels instead of ~30 launches:
+// output, in one forward kernel and three backward kernels instead of ~30 launches, for up to four branches of one
+// encoder per launch (hidden_rep + extra_linear_rep and hidden_lib + its head share the minibatch):
 //
 //   slabs (split-K partials of x W1^T)  -> + b1 -> LayerNorm -> LeakyReLU -> Dropout                  (utils.py:57-63)
 //                                       -> Linear(H1, H2) -> LayerNorm -> LeakyReLU -> Dropout         (second FCNN layer)
 //                                       -> Linear(H2, N3)   (extra_linear_rep, model.py:83-84; the library head
 //                                                            Linear(H2, 1), model.py:92; N3 = 0: none)
 //
-// The work is row-local and tiny (2 B H1 H2 flop), so it runs in exact fp32 on the vector units: a half-wave (32 lanes)
-// owns one cell, lane l holds columns 128 c + 4 l .. + 3 of the H1-wide row in registers (c < 8: H1 <= 1024,
-// H1 % 4 == 0), the H2-wide row sits one or two values per lane (H2 <= 64), row reductions are 5-step butterflies
-// inside the half-wave.  W2 is streamed from L2 as float4 rows.  Backward: a row kernel (same layout: gradients of
-// the small tensors as per-workgroup partials, dY1 = gradient of the first-layer product, dz2), a column kernel for
-// dW2 = dz2^T a1 (a1 recomputed from the saved xhat1), and a fixed-order reduction of the partials.
+// The work is row-local and tiny (2 B H1 H2 flop), so it runs in exact fp32 on the vector units.  A wave owns FOUR
+// cells: every row of W2 it loads from L2 is used four times, and the four dot products of a W2 row are reduced
+// across the wave together.  Backward: a row kernel (same layout: gradients of the small tensors as per-wave
+// partial records, dY1 = gradient of the first-layer product -- fp32 and / or transposed bf16, the operand of the
+// first-layer weight-gradient kernel -- and dz2), a column kernel for dW2 = dz2^T a1 (a1 recomputed from the saved
+// xhat1), and a fixed-order reduction of the partials.
+#include <type_traits>
 #include "common.h"
 #include "scpair_hip.h"
 
-#define ET_NCH 8
-#define ET_ROWS 8
+#define ET_NCH 4        // chunks of 256 columns per row (H1 <= 1024)
+#define ET_RW 2         // cells per wave (1, 2 or 4)
+#define ET_QN (64 / ET_RW)
+#define ET_LG (ET_RW == 4 ? 2 : (ET_RW == 2 ? 1 : 0))
+#define ET_WAVES 2      // waves per workgroup
 typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct TailSet {
+  ScpEncTail b[SCP_ENC_TAIL_MAX_BRANCHES];
+};
 
 __device__ __forceinline__ float leaky_(float z, float slope) { return z > 0.f ? z : z * slope; }
 __device__ __forceinline__ float f4sum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
@@ -39,15 +48,53 @@ __device__ __forceinline__ f4 dleaky4(f4 z, f4 gq, float slope) {
   r.z = z.z > 0.f ? gq.z : gq.z * slope; r.w = z.w > 0.f ? gq.w : gq.w * slope;
   return r;
 }
+__device__ __forceinline__ float lane_bcast(float v, int src) {       // src uniform across the wave
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 
-// Hot loops carry no branch: the chunk count is a template parameter and the loops over the H2 rows of W2 are plain
-// runtime loops (an `if` inside an unrolled loop, even a uniform one, ends a basic block, and the loads of a block
-// are waited for at its end -- the ~400 L2 loads of a lane then run one after the other).  Lanes of the last chunk
-// that lie past H1 read a clamped, valid address and mask the value.
+// RW per-lane values, each summed over the RW lanes that differ in the low log2(RW) bits ("transposing": lane with
+// (lane & (RW-1)) = i gets the sum of value i).  RW = 1, 2 or 4.
+template <int RW> __device__ __forceinline__ float low_tsum(const float (&v)[RW], int lane) {
+  if constexpr (RW == 1) {
+    return v[0];
+  } else if constexpr (RW == 2) {
+    const bool o1 = lane & 1;
+    const float a = o1 ? v[1] : v[0], sa = o1 ? v[0] : v[1];
+    return a + dppf<0xB1>(sa);
+  } else {
+    const bool o1 = lane & 1, o2 = lane & 2;
+    float a = o1 ? v[1] : v[0], sa = o1 ? v[0] : v[1];
+    float b = o1 ? v[3] : v[2], sb = o1 ? v[2] : v[3];
+    a += dppf<0xB1>(sa);
+    b += dppf<0xB1>(sb);
+    const float k = o2 ? b : a, sk = o2 ? a : b;
+    return k + dppf<0x4E>(sk);
+  }
+}
+// sum over the 64 / RW lanes with the same (lane & (RW-1)): quad steps and two rotations inside the row of 16, then
+// across the four rows
+template <int RW> __device__ __forceinline__ float cell_sum(float v) {
+  if constexpr (RW == 1) v += dppf<0xB1>(v);
+  if constexpr (RW <= 2) v += dppf<0x4E>(v);
+  v += dppf<0x128>(v);
+  v += dppf<0x124>(v);
+  return xor32_sum(xor16_sum(v));
+}
+// RW per-lane values summed over the whole wave: every lane returns the total of value (lane & (RW-1)).
+template <int RW> __device__ __forceinline__ float reduce_rw(const float (&v)[RW], int lane) {
+  return cell_sum<RW>(low_tsum<RW>(v, lane));
+}
+
+// Layouts inside a wave (RW cells, RW = 1, 2 or 4; QN = 64 / RW):
+//   wide rows (H1):   lane l holds columns 256 c + 4 l .. + 3 (c < NCH) of ALL the wave's cells;
+//   narrow rows (H2, N3 <= 64): lane l holds cell (l & (RW-1)), columns QN i + (l / RW), i < RW.
+// The loops over the rows of W2 carry no branch (a branch, even a uniform one, ends a basic block and the loads of a
+// block are waited for at its end): the chunk count is a template parameter, lanes past H1 read a clamped address and
+// mask the value, and the H2 loop is a runtime loop inside at most RW blocks of QN columns.
 struct TailOff {
   int g1, be1, b1, g2, be2, b2, w3, b3, pv;
 };
-// Layout of one workgroup's partial-gradient record (PV floats, PV % 4 == 0):
+// Layout of one wave's partial-gradient record (PV floats, PV % 4 == 0):
 //   dgamma1[H1] dbeta1[H1] dbias1[H1] dgamma2[H2] dbeta2[H2] dbias2[H2] dW3[N3*H2] db3[N3]
 static __host__ __device__ inline TailOff tail_off(int H1, int H2, int N3) {
   TailOff o;
@@ -56,316 +103,490 @@ static __host__ __device__ inline TailOff tail_off(int H1, int H2, int N3) {
   o.pv = (o.b3 + N3 + 3) / 4 * 4;
   return o;
 }
+#define ETW_ROWS 64
+// workspace of one branch: records [nrec][pv] | dW2 slabs [nchunk][H2*H1] | dz2 [B][H2]
+struct TailWs {
+  int nrec, nchunk;
+  long wn, o_slab, o_dz2, total;
+};
+static __host__ __device__ inline TailWs tail_ws(int B, int H1, int H2, int N3) {
+  TailWs w;
+  w.nrec = (B + ET_RW - 1) / ET_RW;
+  w.nchunk = (B + ETW_ROWS - 1) / ETW_ROWS;
+  w.wn = (long)H2 * H1;
+  w.o_slab = (long)w.nrec * tail_off(H1, H2, N3).pv;
+  w.o_dz2 = w.o_slab + w.nchunk * w.wn;
+  w.total = w.o_dz2 + (long)B * H2 + 8;
+  return w;
+}
+
+// W3 [N3][H2] and b3 into LDS as [n][65] + [64]; every thread of the workgroup takes part
+__device__ __forceinline__ void stage_w3(const ScpEncTail& m, float* W3s, int tid, int nthreads) {
+  const int nw = m.N3 * m.H2;
+  for (int idx = tid; idx < nw; idx += nthreads) {
+    const int n = idx / m.H2, j = idx - n * m.H2;
+    W3s[n * 65 + j] = m.W3[idx];
+  }
+  for (int idx = tid; idx < m.N3; idx += nthreads) W3s[64 * 65 + idx] = m.b3[idx];
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int NCH>
-__global__ __launch_bounds__(256) void enc_tail_fwd_kernel(ScpEncTail m, const float* __restrict__ slabs, long slab_stride,
-                                                           int nslab, float* __restrict__ out, long ldo) {
-  __shared__ float red[ET_ROWS][32][33];         // partial dot products of 32 rows of W2: [cell][j][lane]
-  const int tid = threadIdx.x, lane = tid & 31, sub = tid >> 5;
-  const int row_ = blockIdx.x * ET_ROWS + sub;
-  const bool live = row_ < m.B;
-  const int row = live ? row_ : m.B - 1;        // dead half-waves recompute the last row and store nothing
-  const int H1 = m.H1, H2 = m.H2, N3 = m.N3;
-  const uint64_t sd1 = m.seed1 + (m.seed_dev ? m.seed_dev[0] : 0), sd2 = m.seed2 + (m.seed_dev ? m.seed_dev[0] : 0);
-  const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
-  bool ok[NCH];
-  int ko[NCH];                                  // clamped column offset of this lane's float4 in chunk c
-  f4 v[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    const int k = c * 128 + lane * 4;
-    ok[c] = k < H1;
-    ko[c] = min(k, H1 - 4);
-    v[c] = zero4;
-  }
-  if (m.b1) {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) v[c] = *(const f4*)(m.b1 + ko[c]);
-  }
-  f4 gam[NCH], bet[NCH];                        // issued ahead of the slab loads: nothing later waits on them alone
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    gam[c] = *(const f4*)(m.g1 + ko[c]);
-    bet[c] = *(const f4*)(m.be1 + ko[c]);
-  }
-  // split-K slabs of the first-layer product, summed in ascending order; four slabs of loads in flight
-  {
-    const float* base = slabs + (long)row * H1;
-    int sl = 0;
-    for (; sl + 4 <= nslab; sl += 4) {
-      f4 t[4][NCH];
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) t[u][c] = *(const f4*)(base + (long)(sl + u) * slab_stride + ko[c]);
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) v[c] += t[u][c];
-    }
-    for (; sl < nslab; sl++) {
-      f4 t[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) t[c] = *(const f4*)(base + (long)sl * slab_stride + ko[c]);
-#pragma unroll
-      for (int c = 0; c < NCH; c++) v[c] += t[c];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < NCH; c++) v[c] = ok[c] ? v[c] : zero4;
-  // LayerNorm 1 (two-pass statistics, biased variance: nn.LayerNorm)
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) s += f4sum(v[c]);
-  const float mean1 = half_sum(s) / (float)H1;
-  float q = 0.f;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    const f4 d = ok[c] ? v[c] - mean1 : zero4;
-    q += f4sum(d * d);
-  }
-  const float rstd1 = 1.f / sqrtf(half_sum(q) / (float)H1 + m.eps1);
-  if (lane == 0 && m.rstd1 && live) m.rstd1[row] = rstd1;
-  f4 a[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    const f4 xh = (v[c] - mean1) * rstd1;
-    if (m.xhat1 && ok[c] && live) *(f4*)(m.xhat1 + (long)row * H1 + ko[c]) = xh;
-    const f4 z = xh * gam[c] + bet[c];
-    const f4 t = leaky4(z, m.slope) * keep4(sd1, (uint64_t)row * H1 + ko[c], m.p1);
-    a[c] = ok[c] ? t : zero4;
-  }
-  // second layer: z2[j] = a1 . W2[j] + b2[j].  Every lane forms its partial dot product with each row of W2 (independent
-  // loads, four rows in flight) and parks it in LDS; lane j then adds the 32 partials of row j (and of row j + 32).
-  const bool vlo = lane < H2, vhi = lane + 32 < H2;
-  float z2lo = 0.f, z2hi = 0.f;
-  for (int half = 0; half * 32 < H2; half++) {
-    const int jn = min(32, H2 - half * 32);
-    if (half) __syncthreads();                  // the first half's readers are done
-#pragma unroll 4
-    for (int jj = 0; jj < jn; jj++) {
-      const float* w = m.W2 + (long)(half * 32 + jj) * H1;
-      float acc = 0.f;
-#pragma unroll
-      for (int c = 0; c < NCH; c++) acc += f4sum(a[c] * *(const f4*)(w + ko[c]));      // a[c] = 0 in masked lanes
-      red[sub][jj][lane] = acc;
-    }
-    __syncthreads();
-    const int jr = min(lane, jn - 1);
-    float tot = 0.f;
-#pragma unroll
-    for (int l = 0; l < 32; l++) tot += red[sub][jr][l];
-    tot += m.b2[min(half * 32 + lane, H2 - 1)];
-    if (half == 0) z2lo = vlo ? tot : 0.f;
-    else z2hi = vhi ? tot : 0.f;
-  }
-  const float mean2 = half_sum(z2lo + z2hi) / (float)H2;
-  const float dlo = vlo ? z2lo - mean2 : 0.f, dhi = vhi ? z2hi - mean2 : 0.f;
-  const float rstd2 = 1.f / sqrtf(half_sum(dlo * dlo + dhi * dhi) / (float)H2 + m.eps2);
-  if (lane == 0 && m.rstd2 && live) m.rstd2[row] = rstd2;
-  const int jlo = min(lane, H2 - 1), jhi = min(lane + 32, H2 - 1);
-  const float xhlo = dlo * rstd2, xhhi = dhi * rstd2;
-  if (m.xhat2 && live) {
-    if (vlo) m.xhat2[(long)row * H2 + lane] = xhlo;
-    if (vhi) m.xhat2[(long)row * H2 + lane + 32] = xhhi;
-  }
-  float x2lo = leaky_(xhlo * m.g2[jlo] + m.be2[jlo], m.slope) * keep_scale(sd2, (uint64_t)row * H2 + jlo, m.p2);
-  float x2hi = leaky_(xhhi * m.g2[jhi] + m.be2[jhi], m.slope) * keep_scale(sd2, (uint64_t)row * H2 + jhi, m.p2);
-  x2lo = vlo ? x2lo : 0.f;
-  x2hi = vhi ? x2hi : 0.f;
-  if (N3 == 0) {
-    if (live) {
-      if (vlo) out[(long)row * ldo + lane] = x2lo;
-      if (vhi) out[(long)row * ldo + lane + 32] = x2hi;
-    }
-    return;
-  }
-  // final Linear(H2, N3): lane n computes outputs n and n + 32 (clamped rows of W3: the loads stay unpredicated)
-  const int nlo = min(lane, N3 - 1), nhi = min(lane + 32, N3 - 1);
-  float olo = m.b3[nlo], ohi = m.b3[nhi];
-  const float* w3lo = m.W3 + (long)nlo * H2;
-  const float* w3hi = m.W3 + (long)nhi * H2;
-#pragma unroll 8
-  for (int k = 0; k < H2; k++) {
-    const float xk = __shfl(k < 32 ? x2lo : x2hi, k & 31, 32);
-    olo += xk * w3lo[k];
-    ohi += xk * w3hi[k];
-  }
-  if (live) {
-    if (lane < N3) out[(long)row * ldo + lane] = olo;
-    if (lane + 32 < N3) out[(long)row * ldo + lane + 32] = ohi;
-  }
-}
-
-template <int NCH>
-__global__ __launch_bounds__(256) void enc_tail_bwd_kernel(ScpEncTail m, const float* __restrict__ dOut, long lddo,
-                                                           float* __restrict__ dY1, long ldy, float* __restrict__ dz2g,
-                                                           float* __restrict__ part) {
-  __shared__ float sh_do[ET_ROWS][64];
-  __shared__ float sh_a2[ET_ROWS][64];
-  __shared__ float sh_v2[ET_ROWS][3][64];
-  __shared__ __attribute__((aligned(16))) float colA[ET_ROWS][NCH * 128];   // one column-sum staging buffer, used 3x
-  const int tid = threadIdx.x, lane = tid & 31, sub = tid >> 5;
-  const int row_ = blockIdx.x * ET_ROWS + sub;
-  const bool live = row_ < m.B;
-  const int row = live ? row_ : m.B - 1;          // dead half-waves recompute the last row; their results are zeroed
-  const float lv = live ? 1.f : 0.f;
-  const int H1 = m.H1, H2 = m.H2, N3 = m.N3;
-  const int NO = N3 > 0 ? N3 : H2;                 // width of dOut
-  const TailOff off = tail_off(H1, H2, N3);
+__global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) {
+  __shared__ float W3s[64 * 65 + 64];
+  const ScpEncTail& m = S.b[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int H1 = m.H1, H2 = m.H2, N3 = m.N3, B = m.B;
+  if (N3 > 0) stage_w3(m, W3s, tid, 64 * ET_WAVES);
+  __syncthreads();
+  const int row0 = (blockIdx.x * ET_WAVES + wv) * ET_RW;
+  if (row0 >= B) return;                          // no barrier below
   const uint64_t sd1 = m.seed1 + (m.seed_dev ? m.seed_dev[0] : 0), sd2 = m.seed2 + (m.seed_dev ? m.seed_dev[0] : 0);
   const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
   bool ok[NCH];
   int ko[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    ok[c] = c * 128 + lane * 4 < H1;
-    ko[c] = min(c * 128 + lane * 4, H1 - 4);
+    const int k = c * 256 + lane * 4;
+    ok[c] = k < H1;
+    ko[c] = min(k, H1 - 4);
   }
-  const bool vlo = lane < H2, vhi = lane + 32 < H2;
-  const int jlo = min(lane, H2 - 1), jhi = min(lane + 32, H2 - 1);
-  const int olo_i = min(lane, NO - 1), ohi_i = min(lane + 32, NO - 1);
-  const float dolo = lane < NO ? lv * dOut[(long)row * lddo + olo_i] : 0.f;
-  const float dohi = lane + 32 < NO ? lv * dOut[(long)row * lddo + ohi_i] : 0.f;
-  const float r2 = m.rstd2[row];
-  const float xlo = vlo ? m.xhat2[(long)row * H2 + jlo] : 0.f, xhi = vhi ? m.xhat2[(long)row * H2 + jhi] : 0.f;
-  const float glo = vlo ? m.g2[jlo] : 0.f, ghi = vhi ? m.g2[jhi] : 0.f;
-  const float znlo = xlo * glo + m.be2[jlo], znhi = xhi * ghi + m.be2[jhi];
-  const float klo = vlo ? keep_scale(sd2, (uint64_t)row * H2 + jlo, m.p2) : 0.f;
-  const float khi = vhi ? keep_scale(sd2, (uint64_t)row * H2 + jhi, m.p2) : 0.f;
-  const float a2lo = leaky_(znlo, m.slope) * klo * lv, a2hi = leaky_(znhi, m.slope) * khi * lv;
-  float dalo = 0.f, dahi = 0.f;                   // gradient wrt a2
+  int rowc[ET_RW];
+  bool live[ET_RW];
+#pragma unroll
+  for (int r = 0; r < ET_RW; r++) {
+    live[r] = row0 + r < B;
+    rowc[r] = min(row0 + r, B - 1);               // cells past the batch end recompute the last one and store nothing
+  }
+  f4 v[ET_RW][NCH];
+  f4 gam[NCH], bet[NCH];                          // issued ahead of the slab loads: nothing later waits on them alone
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const f4 b = m.b1 ? *(const f4*)(m.b1 + ko[c]) : zero4;
+#pragma unroll
+    for (int r = 0; r < ET_RW; r++) v[r][c] = b;
+    gam[c] = *(const f4*)(m.g1 + ko[c]);
+    bet[c] = *(const f4*)(m.be1 + ko[c]);
+  }
+  // split-K slabs of the first-layer product, summed in ascending order; two slabs (2 x 4 x NCH loads) in flight
+  {
+    const float* base[ET_RW];
+#pragma unroll
+    for (int r = 0; r < ET_RW; r++) base[r] = m.slabs + (long)rowc[r] * m.ld_slab;
+    int sl = 0;
+    for (; sl + 2 <= m.nslab; sl += 2) {
+      f4 t[2][ET_RW][NCH];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < ET_RW; r++)
+#pragma unroll
+          for (int c = 0; c < NCH; c++) t[u][r][c] = *(const f4*)(base[r] + (long)(sl + u) * m.slab_stride + ko[c]);
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < ET_RW; r++)
+#pragma unroll
+          for (int c = 0; c < NCH; c++) v[r][c] += t[u][r][c];
+    }
+    if (sl < m.nslab) {
+      f4 t[ET_RW][NCH];
+#pragma unroll
+      for (int r = 0; r < ET_RW; r++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) t[r][c] = *(const f4*)(base[r] + (long)sl * m.slab_stride + ko[c]);
+#pragma unroll
+      for (int r = 0; r < ET_RW; r++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) v[r][c] += t[r][c];
+    }
+  }
+  // LayerNorm 1 (two-pass statistics, biased variance: nn.LayerNorm), activation, dropout
+  float part[ET_RW];
+#pragma unroll
+  for (int r = 0; r < ET_RW; r++) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      v[r][c] = ok[c] ? v[r][c] : zero4;
+      s += f4sum(v[r][c]);
+    }
+    part[r] = s;
+  }
+  const float ssum = reduce_rw<ET_RW>(part, lane);
+  float mean1[ET_RW];
+#pragma unroll
+  for (int r = 0; r < ET_RW; r++) {
+    mean1[r] = lane_bcast(ssum, r) / (float)H1;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const f4 d = ok[c] ? v[r][c] - mean1[r] : zero4;
+      q += f4sum(d * d);
+    }
+    part[r] = q;
+  }
+  const float qsum = reduce_rw<ET_RW>(part, lane);
+  f4 a[ET_RW][NCH];
+#pragma unroll
+  for (int r = 0; r < ET_RW; r++) {
+    const float rstd1 = 1.f / sqrtf(lane_bcast(qsum, r) / (float)H1 + m.eps1);
+    if (lane == 0 && m.rstd1 && live[r]) m.rstd1[rowc[r]] = rstd1;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const f4 xh = (v[r][c] - mean1[r]) * rstd1;
+      if (m.xhat1 && ok[c] && live[r]) *(f4*)(m.xhat1 + (long)rowc[r] * H1 + ko[c]) = xh;
+      const f4 z = xh * gam[c] + bet[c];
+      const f4 t = leaky4(z, m.slope) * keep4(sd1, (uint64_t)rowc[r] * H1 + ko[c], m.p1);
+      a[r][c] = ok[c] ? t : zero4;
+    }
+  }
+  // second layer: z2[cell][j] = a1[cell] . W2[j] + b2[j]; the wave streams the rows of W2 (independent loads, four
+  // rows in flight) and forms the four cells' dot products with each
+  const int zc = lane & (ET_RW - 1), q = lane >> ET_LG;      // narrow layout: my cell, my column residue
+  const int rowz = min(row0 + zc, B - 1);
+  const bool livez = row0 + zc < B;
+  float zr[ET_RW];
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) zr[i] = 0.f;
+#pragma unroll
+  for (int jb = 0; jb < ET_RW; jb++) {
+    if (jb * ET_QN < H2) {                        // uniform
+      const int jn = min(ET_QN, H2 - jb * ET_QN);
+      float zk = 0.f;
+      // U rows of W2 per trip: their loads are issued together (the compiler does not unroll a loop of unknown trip
+      // count on request, and one row per trip exposes the full L2 latency forty times)
+      auto rows_of_w2 = [&](auto u_c, int jj) {
+        constexpr int U = decltype(u_c)::value;
+        f4 wr[U][NCH];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int c = 0; c < NCH; c++) wr[u][c] = *(const f4*)(m.W2 + (long)(jb * ET_QN + jj + u) * H1 + ko[c]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          float p[ET_RW];
+#pragma unroll
+          for (int r = 0; r < ET_RW; r++) {
+            f4 acc = a[r][0] * wr[u][0];          // a = 0 in masked lanes
+#pragma unroll
+            for (int c = 1; c < NCH; c++) acc += a[r][c] * wr[u][c];
+            p[r] = f4sum(acc);
+          }
+          const float k = reduce_rw<ET_RW>(p, lane);
+          zk = (jj + u == q) ? k : zk;
+        }
+      };
+      int jj = 0;
+      for (; jj + 4 <= jn; jj += 4) rows_of_w2(std::integral_constant<int, 4>{}, jj);
+      for (; jj < jn; jj++) rows_of_w2(std::integral_constant<int, 1>{}, jj);
+      zr[jb] = zk;
+    }
+  }
+  bool vz[ET_RW];
+  int jc[ET_RW];
+  float xh2[ET_RW];
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) {
+    vz[i] = ET_QN * i + q < H2;
+    jc[i] = min(ET_QN * i + q, H2 - 1);
+    zr[i] = vz[i] ? zr[i] + m.b2[jc[i]] : 0.f;
+    s2 += zr[i];
+  }
+  const float mean2 = cell_sum<ET_RW>(s2) / (float)H2;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) {
+    xh2[i] = vz[i] ? zr[i] - mean2 : 0.f;
+    q2 += xh2[i] * xh2[i];
+  }
+  const float rstd2 = 1.f / sqrtf(cell_sum<ET_RW>(q2) / (float)H2 + m.eps2);
+  if (q == 0 && m.rstd2 && livez) m.rstd2[rowz] = rstd2;
+  float x2[ET_RW];
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) {
+    xh2[i] *= rstd2;
+    if (m.xhat2 && vz[i] && livez) m.xhat2[(long)rowz * H2 + jc[i]] = xh2[i];
+    const float t = leaky_(xh2[i] * m.g2[jc[i]] + m.be2[jc[i]], m.slope) * keep_scale(sd2, (uint64_t)rowz * H2 + jc[i], m.p2);
+    x2[i] = vz[i] ? t : 0.f;
+  }
+  if (N3 == 0) {
+#pragma unroll
+    for (int i = 0; i < ET_RW; i++)
+      if (vz[i] && livez) m.out[(long)rowz * m.ldo + jc[i]] = x2[i];
+    return;
+  }
+  // final Linear(H2, N3): a lane forms the partial dot product over its columns, the cell's 16 lanes add up
+  float o[ET_RW];
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) o[i] = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < ET_RW; nb++) {
+    if (nb * ET_QN < N3) {
+      const int nn_ = min(ET_QN, N3 - nb * ET_QN);
+      float ok_ = 0.f;
+      auto rows_of_w3 = [&](auto u_c, int nn) {
+        constexpr int U = decltype(u_c)::value;
+        float pr[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const float* w = W3s + (nb * ET_QN + nn + u) * 65;
+          pr[u] = x2[0] * w[jc[0]];
+#pragma unroll
+          for (int i = 1; i < ET_RW; i++) pr[u] += x2[i] * w[jc[i]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const float tot = cell_sum<ET_RW>(pr[u]);
+          ok_ = (nn + u == q) ? tot : ok_;
+        }
+      };
+      int nn = 0;
+      for (; nn + 4 <= nn_; nn += 4) rows_of_w3(std::integral_constant<int, 4>{}, nn);
+      for (; nn < nn_; nn++) rows_of_w3(std::integral_constant<int, 1>{}, nn);
+      o[nb] = ok_;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) {
+    const int n = ET_QN * i + q;
+    if (n < N3 && livez) m.out[(long)rowz * m.ldo + n] = o[i] + W3s[64 * 65 + n];
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) {
+  __shared__ float W3s[64 * 65 + 64];
+  const ScpEncTail& m = S.b[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int H1 = m.H1, H2 = m.H2, N3 = m.N3, B = m.B;
+  if (N3 > 0) stage_w3(m, W3s, tid, 64 * ET_WAVES);
+  __syncthreads();
+  const int rec_i = blockIdx.x * ET_WAVES + wv;
+  const int row0 = rec_i * ET_RW;
+  if (row0 >= B) return;                          // no barrier below
+  const int NO = N3 > 0 ? N3 : H2;                 // width of dOut
+  const TailOff off = tail_off(H1, H2, N3);
+  const TailWs wsl = tail_ws(B, H1, H2, N3);
+  float* rec = m.ws + (long)rec_i * off.pv;
+  float* dz2g = m.ws + wsl.o_dz2;
+  const uint64_t sd1 = m.seed1 + (m.seed_dev ? m.seed_dev[0] : 0), sd2 = m.seed2 + (m.seed_dev ? m.seed_dev[0] : 0);
+  const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+  bool ok[NCH];
+  int ko[NCH];
+  f4 gam[NCH], bet[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    ok[c] = c * 256 + lane * 4 < H1;
+    ko[c] = min(c * 256 + lane * 4, H1 - 4);
+    gam[c] = *(const f4*)(m.g1 + ko[c]);
+    bet[c] = *(const f4*)(m.be1 + ko[c]);
+  }
+  // ---- narrow part: cell (lane & (RW-1)), columns QN i + lane / RW --------------------------------------------
+  const int zc = lane & (ET_RW - 1), q = lane >> ET_LG;
+  const int rowz = min(row0 + zc, B - 1);
+  const bool livez = row0 + zc < B;                // a dead cell has dOut = 0, hence every gradient of it is 0
+  bool vz[ET_RW];
+  int jc[ET_RW];
+  float dor[ET_RW], xh2[ET_RW], g2v[ET_RW], zn[ET_RW], kp[ET_RW], a2[ET_RW];
+  const float r2 = m.rstd2[rowz];
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) {
+    const int j = ET_QN * i + q;
+    vz[i] = j < H2;
+    jc[i] = min(j, H2 - 1);
+    dor[i] = (j < NO && livez) ? m.dOut[(long)rowz * m.lddo + min(j, NO - 1)] : 0.f;
+    xh2[i] = vz[i] ? m.xhat2[(long)rowz * H2 + jc[i]] : 0.f;
+    g2v[i] = vz[i] ? m.g2[jc[i]] : 0.f;
+    zn[i] = xh2[i] * g2v[i] + m.be2[jc[i]];
+    kp[i] = vz[i] ? keep_scale(sd2, (uint64_t)rowz * H2 + jc[i], m.p2) : 0.f;
+    a2[i] = leaky_(zn[i], m.slope) * kp[i];
+  }
+  float da2[ET_RW];
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) da2[i] = 0.f;
   if (N3 > 0) {
-#pragma unroll 8
-    for (int n = 0; n < N3; n++) {
-      const float dn = __shfl(n < 32 ? dolo : dohi, n & 31, 32);
-      dalo += dn * m.W3[(long)n * H2 + jlo];
-      dahi += dn * m.W3[(long)n * H2 + jhi];
+    // da2[cell][j] = sum_n dOut[cell][n] W3[n][j];  dW3[n][j] += sum over the wave's cells of dOut[cell][n] a2[cell][j]
+#pragma unroll
+    for (int nb = 0; nb < ET_RW; nb++) {
+      if (nb * ET_QN < N3) {
+        const int nn_ = min(ET_QN, N3 - nb * ET_QN);
+        for (int nn = 0; nn < nn_; nn++) {
+          const int n = nb * ET_QN + nn;
+          float dn = lane_bcast(dor[nb], ET_RW * nn);                  // dOut[my cell][n]: lane (cell, q = nn) holds it
+#pragma unroll
+          for (int cc = 1; cc < ET_RW; cc++) {
+            const float dcc = lane_bcast(dor[nb], ET_RW * nn + cc);
+            dn = (zc == cc) ? dcc : dn;
+          }
+          const float* w = W3s + n * 65;
+#pragma unroll
+          for (int i = 0; i < ET_RW; i++) da2[i] += dn * w[jc[i]];
+          float pw[ET_RW];
+#pragma unroll
+          for (int i = 0; i < ET_RW; i++) pw[i] = dn * a2[i];
+          const float t = low_tsum<ET_RW>(pw, lane);
+          const int j = ET_QN * zc + q;                           // after the sum lane (i = zc, q) holds column QN i + q
+          if (j < H2) rec[off.w3 + n * H2 + j] = t;
+        }
+      }
     }
+    const float tb = low_tsum<ET_RW>(dor, lane);
+    if (ET_QN * zc + q < N3) rec[off.b3 + ET_QN * zc + q] = tb;
   } else {
-    dalo = dolo;
-    dahi = dohi;
+#pragma unroll
+    for (int i = 0; i < ET_RW; i++) da2[i] = dor[i];
   }
-  sh_do[sub][lane] = dolo; sh_do[sub][lane + 32] = dohi;
-  sh_a2[sub][lane] = a2lo; sh_a2[sub][lane + 32] = a2hi;
   // LayerNorm 2 / activation / dropout backward
-  const float gq_lo = dalo * klo, gq_hi = dahi * khi;
-  const float dzlo = vlo ? (znlo > 0.f ? gq_lo : gq_lo * m.slope) : 0.f;
-  const float dzhi = vhi ? (znhi > 0.f ? gq_hi : gq_hi * m.slope) : 0.f;
-  const float dxlo = dzlo * glo, dxhi = dzhi * ghi;
-  const float s1 = half_sum(dxlo + dxhi) / (float)H2;
-  const float s2 = half_sum(dxlo * xlo + dxhi * xhi) / (float)H2;
-  const float d2lo = vlo ? r2 * (dxlo - s1 - xlo * s2) : 0.f, d2hi = vhi ? r2 * (dxhi - s1 - xhi * s2) : 0.f;
-  sh_v2[sub][0][lane] = dzlo * xlo; sh_v2[sub][0][lane + 32] = dzhi * xhi;
-  sh_v2[sub][1][lane] = dzlo;       sh_v2[sub][1][lane + 32] = dzhi;
-  sh_v2[sub][2][lane] = d2lo;       sh_v2[sub][2][lane + 32] = d2hi;
-  if (live) {
-    if (vlo) dz2g[(long)row * H2 + lane] = d2lo;
-    if (vhi) dz2g[(long)row * H2 + lane + 32] = d2hi;
+  float dz[ET_RW], dx[ET_RW], d2[ET_RW];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) {
+    const float gq = da2[i] * kp[i];
+    dz[i] = vz[i] ? (zn[i] > 0.f ? gq : gq * m.slope) : 0.f;
+    dx[i] = dz[i] * g2v[i];
+    s1 += dx[i];
+    s2 += dx[i] * xh2[i];
   }
-  // gradient wrt a1: da[k] = sum_j dz2[j] W2[j][k]  (rows of W2: independent loads, four rows in flight)
-  f4 da[NCH];
+  s1 = cell_sum<ET_RW>(s1) / (float)H2;
+  s2 = cell_sum<ET_RW>(s2) / (float)H2;
 #pragma unroll
-  for (int c = 0; c < NCH; c++) da[c] = zero4;
-#pragma unroll 4
-  for (int j = 0; j < H2; j++) {
-    const float dzj = __shfl(j < 32 ? d2lo : d2hi, j & 31, 32);
-    const float* w = m.W2 + (long)j * H1;
-#pragma unroll
-    for (int c = 0; c < NCH; c++) da[c] += dzj * *(const f4*)(w + ko[c]);
+  for (int i = 0; i < ET_RW; i++) {
+    d2[i] = vz[i] ? r2 * (dx[i] - s1 - xh2[i] * s2) : 0.f;
+    if (vz[i] && livez) dz2g[(long)rowz * H2 + jc[i]] = d2[i];
   }
-  // LayerNorm 1 / activation / dropout backward
-  const float r1 = m.rstd1[row];
-  f4 xh[NCH], dxh[NCH], cb[NCH], cd[NCH];
-  float t1 = 0.f, t2 = 0.f;
+  {
+    float pg[ET_RW];
 #pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    const f4 xl = *(const f4*)(m.xhat1 + (long)row * H1 + ko[c]);
-    const f4 gam = *(const f4*)(m.g1 + ko[c]);
-    const f4 z = xl * gam + *(const f4*)(m.be1 + ko[c]);
-    const f4 dzl = dleaky4(z, da[c] * keep4(sd1, (uint64_t)row * H1 + ko[c], m.p1), m.slope);
-    const f4 dz = ok[c] ? dzl : zero4;           // dead rows: dz2 = 0, hence da = 0 and dz = 0
-    xh[c] = ok[c] ? xl : zero4;
-    cb[c] = dz;
-    dxh[c] = dz * gam;
-    t1 += f4sum(dxh[c]);
-    t2 += f4sum(dxh[c] * xh[c]);
-    *(f4*)&colA[sub][c * 128 + lane * 4] = dz * xh[c];
-  }
-  t1 = half_sum(t1) / (float)H1;
-  t2 = half_sum(t2) / (float)H1;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    cd[c] = ok[c] ? (dxh[c] - t1 - xh[c] * t2) * r1 : zero4;
-    if (ok[c] && live) *(f4*)(dY1 + (long)row * ldy + ko[c]) = cd[c];
-  }
-  __syncthreads();
-  float* rec = part + (long)blockIdx.x * off.pv;
-  // column sums over the workgroup's rows (fixed order)
-  if (tid * 4 < H1) {
-    f4 sa = zero4;
-#pragma unroll
-    for (int r = 0; r < ET_ROWS; r++) sa += *(const f4*)&colA[r][tid * 4];
-    *(f4*)(rec + off.g1 + tid * 4) = sa;
-  }
-  if (tid < H2) {
-    float s0 = 0.f, s1_ = 0.f, s2_ = 0.f;
-#pragma unroll
-    for (int r = 0; r < ET_ROWS; r++) {
-      s0 += sh_v2[r][0][tid];
-      s1_ += sh_v2[r][1][tid];
-      s2_ += sh_v2[r][2][tid];
+    for (int i = 0; i < ET_RW; i++) pg[i] = dz[i] * xh2[i];
+    const float tg = low_tsum<ET_RW>(pg, lane);
+    const float tb = low_tsum<ET_RW>(dz, lane);
+    const float td = low_tsum<ET_RW>(d2, lane);
+    const int j = ET_QN * zc + q;
+    if (j < H2) {
+      rec[off.g2 + j] = tg;
+      rec[off.be2 + j] = tb;
+      rec[off.b2 + j] = td;
     }
-    rec[off.g2 + tid] = s0;
-    rec[off.be2 + tid] = s1_;
-    rec[off.b2 + tid] = s2_;
   }
-  for (int idx = tid; idx < N3 * H2; idx += 256) {
-    const int n = idx / H2, j = idx - n * H2;
-    float s0 = 0.f;
+  // ---- wide part: gradient wrt a1: da[cell][k] = sum_j dz2[cell][j] W2[j][k] ------------------------------------
+  f4 da[ET_RW][NCH];
 #pragma unroll
-    for (int r = 0; r < ET_ROWS; r++) s0 += sh_do[r][n] * sh_a2[r][j];
-    rec[off.w3 + idx] = s0;
+  for (int r = 0; r < ET_RW; r++)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) da[r][c] = zero4;
+#pragma unroll
+  for (int jb = 0; jb < ET_RW; jb++) {
+    if (jb * ET_QN < H2) {
+      const int jn = min(ET_QN, H2 - jb * ET_QN);
+      auto rows_of_w2 = [&](auto u_c, int jj) {
+        constexpr int U = decltype(u_c)::value;
+        f4 wr[U][NCH];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int c = 0; c < NCH; c++) wr[u][c] = *(const f4*)(m.W2 + (long)(jb * ET_QN + jj + u) * H1 + ko[c]);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int r = 0; r < ET_RW; r++) {
+            const float dzj = lane_bcast(d2[jb], r + ET_RW * (jj + u));   // dz2[cell r][QN jb + jj + u]
+#pragma unroll
+            for (int c = 0; c < NCH; c++) da[r][c] += dzj * wr[u][c];
+          }
+      };
+      int jj = 0;
+      for (; jj + 4 <= jn; jj += 4) rows_of_w2(std::integral_constant<int, 4>{}, jj);
+      for (; jj < jn; jj++) rows_of_w2(std::integral_constant<int, 1>{}, jj);
+    }
   }
-  if (tid < N3) {
-    float s0 = 0.f;
+  // LayerNorm 1 / activation / dropout backward; column sums over the wave's cells stay in registers
+  f4 sg[NCH], sb[NCH], sd[NCH];
 #pragma unroll
-    for (int r = 0; r < ET_ROWS; r++) s0 += sh_do[r][tid];
-    rec[off.b3 + tid] = s0;
+  for (int c = 0; c < NCH; c++) sg[c] = sb[c] = sd[c] = zero4;
+  f4 xh[ET_RW][NCH];
+  float t1p[ET_RW], t2p[ET_RW];
+#pragma unroll
+  for (int r = 0; r < ET_RW; r++) {
+    const int row = min(row0 + r, B - 1);
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const f4 xl = *(const f4*)(m.xhat1 + (long)row * H1 + ko[c]);
+      const f4 z = xl * gam[c] + bet[c];
+      const f4 dzl = dleaky4(z, da[r][c] * keep4(sd1, (uint64_t)row * H1 + ko[c], m.p1), m.slope);
+      const f4 dz1 = ok[c] ? dzl : zero4;          // dead cells: dz2 = 0, hence da = 0 and dz1 = 0
+      xh[r][c] = ok[c] ? xl : zero4;
+      sg[c] += dz1 * xh[r][c];
+      sb[c] += dz1;
+      da[r][c] = dz1 * gam[c];                      // from here on: d xhat
+      t1 += f4sum(da[r][c]);
+      t2 += f4sum(da[r][c] * xh[r][c]);
+    }
+    t1p[r] = t1;
+    t2p[r] = t2;
   }
-  __syncthreads();
+  const float t1s = reduce_rw<ET_RW>(t1p, lane);
+  const float t2s = reduce_rw<ET_RW>(t2p, lane);
 #pragma unroll
-  for (int c = 0; c < NCH; c++) *(f4*)&colA[sub][c * 128 + lane * 4] = cb[c];
-  __syncthreads();
-  if (tid * 4 < H1) {
-    f4 sa = zero4;
+  for (int r = 0; r < ET_RW; r++) {
+    const int row = min(row0 + r, B - 1);
+    const bool live = row0 + r < B;
+    const float r1 = m.rstd1[row];
+    const float t1 = lane_bcast(t1s, r) / (float)H1, t2 = lane_bcast(t2s, r) / (float)H1;
 #pragma unroll
-    for (int r = 0; r < ET_ROWS; r++) sa += *(const f4*)&colA[r][tid * 4];
-    *(f4*)(rec + off.be1 + tid * 4) = sa;
+    for (int c = 0; c < NCH; c++) {
+      const f4 cd = ok[c] ? (da[r][c] - t1 - xh[r][c] * t2) * r1 : zero4;
+      da[r][c] = cd;                                // from here on: dY1
+      sd[c] += cd;
+      if (m.dY1 && ok[c] && live) *(f4*)(m.dY1 + (long)row * m.ldy + ko[c]) = cd;
+    }
   }
-  __syncthreads();
+  if (m.dYT) {
+    // transposed bf16 copy [H1][ldt]: the wave's cells are consecutive columns -> one store per row
+    // of dY^T (cells past the batch end hold 0; ldt covers the batch rounded up to 64)
+    __bf16* T = (__bf16*)m.dYT;
 #pragma unroll
-  for (int c = 0; c < NCH; c++) *(f4*)&colA[sub][c * 128 + lane * 4] = cd[c];
-  __syncthreads();
-  if (tid * 4 < H1) {
-    f4 sa = zero4;
+    for (int c = 0; c < NCH; c++) {
+      if (ok[c]) {
 #pragma unroll
-    for (int r = 0; r < ET_ROWS; r++) sa += *(const f4*)&colA[r][tid * 4];
-    *(f4*)(rec + off.b1 + tid * 4) = sa;
+        for (int e = 0; e < 4; e++) {
+          typedef __bf16 bfrw __attribute__((ext_vector_type(ET_RW == 1 ? 2 : ET_RW)));
+          if constexpr (ET_RW == 1) {
+            T[(long)(ko[c] + e) * m.ldt + row0] = (__bf16)da[0][c][e];
+          } else {
+            bfrw o;
+#pragma unroll
+            for (int r = 0; r < ET_RW; r++) o[r] = (__bf16)da[r][c][e];
+            *(bfrw*)(T + (long)(ko[c] + e) * m.ldt + row0) = o;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if (ok[c]) {
+      *(f4*)(rec + off.g1 + ko[c]) = sg[c];
+      *(f4*)(rec + off.be1 + ko[c]) = sb[c];
+      *(f4*)(rec + off.b1 + ko[c]) = sd[c];
+    }
   }
 }
 
 // dW2 slab of one (128-column block, 64-row chunk): slab[chunk][j][k] = sum over the chunk's rows of dz2[row][j] a1[row][k]
-#define ETW_ROWS 64
-__global__ __launch_bounds__(256) void enc_tail_w2_kernel(ScpEncTail m, const float* __restrict__ dz2g,
-                                                          float* __restrict__ slab) {
+__global__ __launch_bounds__(256) void enc_tail_w2_kernel(TailSet S) {
   __shared__ float dzs[ETW_ROWS][64];
   __shared__ __attribute__((aligned(16))) float red[8][8][128];
+  const ScpEncTail& m = S.b[blockIdx.z];
   const int tid = threadIdx.x, kq = tid & 31, slot = tid >> 5;
   const int H1 = m.H1, H2 = m.H2;
+  if (blockIdx.x * 128 >= H1 || !m.dW2) return;    // uniform: a narrower branch of the same launch
+  const TailWs wsl = tail_ws(m.B, H1, H2, m.N3);
+  const float* dz2g = m.ws + wsl.o_dz2;
+  float* slab = m.ws + wsl.o_slab;
   const int k = blockIdx.x * 128 + kq * 4;
-  const bool okk = k < H1;
   const int r0 = blockIdx.y * ETW_ROWS;
   const uint64_t sd1 = m.seed1 + (m.seed_dev ? m.seed_dev[0] : 0);
   for (int idx = tid; idx < ETW_ROWS * 64; idx += 256) {
@@ -374,7 +595,6 @@ __global__ __launch_bounds__(256) void enc_tail_w2_kernel(ScpEncTail m, const fl
   }
   const int kc = min(k, H1 - 4);
   const f4 gam = *(const f4*)(m.g1 + kc), bet = *(const f4*)(m.be1 + kc);
-  (void)okk;
   __syncthreads();
   for (int pass = 0; pass * 32 < H2; pass++) {
     f4 acc[32];
@@ -416,20 +636,25 @@ __global__ __launch_bounds__(256) void enc_tail_w2_kernel(ScpEncTail m, const fl
 struct TailRed {
   const float* part; int nblk; int pv;
   const float* slab; int nchunk; long wn;
-  int nseg; int seg_beg[8]; int seg_end[8]; float* seg_dst[8];
+  int seg_beg[8]; int seg_end[8]; float* seg_dst[8];
   float* dW2;
 };
-__global__ __launch_bounds__(256) void enc_tail_reduce_kernel(TailRed r) {
+struct TailRedSet {
+  TailRed b[SCP_ENC_TAIL_MAX_BRANCHES];
+};
+__global__ __launch_bounds__(256) void enc_tail_reduce_kernel(TailRedSet R) {
   // 64 outputs per workgroup, 4 threads per output: thread (o, q) sums records q, q + 4, ... (eight loads in flight),
   // the four partial sums are combined in a fixed order
   __shared__ float red[4][64];
+  const TailRed& r = R.b[blockIdx.y];
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + o;
+  if ((long)blockIdx.x * 64 >= r.pv + r.wn) return;      // uniform: a smaller branch of the same launch
   const bool in_part = i < r.pv;
   const long w = i - r.pv;
   const float* src = in_part ? r.part + i : r.slab + w;
   const long stride = in_part ? r.pv : r.wn;
-  const int n = in_part ? r.nblk : ((w < r.wn) ? r.nchunk : 0);
+  const int n = in_part ? r.nblk : ((w < r.wn && r.dW2) ? r.nchunk : 0);
   float s = 0.f;
   int b = q;
   for (; b + 28 < n; b += 32) {
@@ -445,91 +670,119 @@ __global__ __launch_bounds__(256) void enc_tail_reduce_kernel(TailRed r) {
   if (q != 0 || n == 0) return;
   s = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
   if (in_part) {
-    for (int g_ = 0; g_ < r.nseg; g_++)
+    for (int g_ = 0; g_ < 8; g_++)
       if (i >= r.seg_beg[g_] && i < r.seg_end[g_] && r.seg_dst[g_]) r.seg_dst[g_][i - r.seg_beg[g_]] = s;
-  } else if (r.dW2) {
+  } else {
     r.dW2[w] = s;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static int tail_check(const ScpEncTail* m, const char* who) {
-  SCP_CHECK(m, SCP_ERR_ARG, "%s: null module description", who);
-  SCP_CHECK(m->B > 0 && m->H1 > 0 && m->H2 > 0 && m->N3 >= 0, SCP_ERR_ARG, "%s: sizes must be positive", who);
-  SCP_CHECK(m->H1 % 4 == 0 && m->H1 >= 4 && m->H1 <= ET_NCH * 128 && m->H2 <= 64 && m->N3 <= 64, SCP_ERR_SHAPE,
-            "%s: needs H1 %% 4 == 0, H1 <= %d, H2 <= 64, N3 <= 64 (got %d, %d, %d)", who, ET_NCH * 128, m->H1, m->H2, m->N3);
-  SCP_CHECK(m->g1 && m->be1 && m->W2 && m->b2 && m->g2 && m->be2, SCP_ERR_ARG, "%s: null parameter pointer", who);
-  SCP_CHECK(m->N3 == 0 || (m->W3 && m->b3), SCP_ERR_ARG, "%s: the final Linear needs weight and bias", who);
-  SCP_CHECK((((uintptr_t)m->b1 | (uintptr_t)m->g1 | (uintptr_t)m->be1 | (uintptr_t)m->W2 | (uintptr_t)m->xhat1) & 15) == 0,
-            SCP_ERR_SHAPE, "%s: H1-wide tensors must be 16-byte aligned", who);
-  SCP_CHECK(m->p1 >= 0.f && m->p1 < 1.f && m->p2 >= 0.f && m->p2 < 1.f, SCP_ERR_ARG, "%s: dropout p must be in [0,1)", who);
+static int tail_check(const ScpEncTail* ms, int nb, const char* who) {
+  SCP_CHECK(ms && nb >= 1 && nb <= SCP_ENC_TAIL_MAX_BRANCHES, SCP_ERR_ARG, "%s: needs 1..%d branch descriptions", who,
+            SCP_ENC_TAIL_MAX_BRANCHES);
+  for (int b = 0; b < nb; b++) {
+    const ScpEncTail* m = ms + b;
+    SCP_CHECK(m->B > 0 && m->H1 > 0 && m->H2 > 0 && m->N3 >= 0, SCP_ERR_ARG, "%s: sizes must be positive", who);
+    SCP_CHECK(m->B == ms[0].B, SCP_ERR_ARG, "%s: the branches of one launch share the minibatch", who);
+    SCP_CHECK(m->H1 % 4 == 0 && m->H1 >= 4 && m->H1 <= ET_NCH * 256 && m->H2 <= 64 && m->N3 <= 64, SCP_ERR_SHAPE,
+              "%s: needs H1 %% 4 == 0, H1 <= %d, H2 <= 64, N3 <= 64 (got %d, %d, %d)", who, ET_NCH * 256, m->H1, m->H2, m->N3);
+    SCP_CHECK(m->g1 && m->be1 && m->W2 && m->b2 && m->g2 && m->be2, SCP_ERR_ARG, "%s: null parameter pointer", who);
+    SCP_CHECK(m->N3 == 0 || (m->W3 && m->b3), SCP_ERR_ARG, "%s: the final Linear needs weight and bias", who);
+    SCP_CHECK((((uintptr_t)m->b1 | (uintptr_t)m->g1 | (uintptr_t)m->be1 | (uintptr_t)m->W2 | (uintptr_t)m->xhat1) & 15) == 0,
+              SCP_ERR_SHAPE, "%s: H1-wide tensors must be 16-byte aligned", who);
+    SCP_CHECK(m->p1 >= 0.f && m->p1 < 1.f && m->p2 >= 0.f && m->p2 < 1.f, SCP_ERR_ARG, "%s: dropout p must be in [0,1)", who);
+  }
   return SCP_OK;
 }
 
-extern "C" int scp_enc_tail_fwd(const ScpEncTail* m, const float* slabs, long slab_stride, int nslab, float* out, long ldo,
-                                void* stream_) {
-  int rc = tail_check(m, "scp_enc_tail_fwd");
+static int tail_nch(const ScpEncTail* ms, int nb) {
+  int h = 0;
+  for (int b = 0; b < nb; b++) h = ms[b].H1 > h ? ms[b].H1 : h;
+  return (h + 255) / 256;
+}
+
+extern "C" int scp_enc_tail_fwd(const ScpEncTail* ms, int nbranch, void* stream_) {
+  int rc = tail_check(ms, nbranch, "scp_enc_tail_fwd");
   if (rc) return rc;
-  SCP_CHECK(slabs && out && nslab > 0 && ldo >= (m->N3 > 0 ? m->N3 : m->H2), SCP_ERR_ARG, "scp_enc_tail_fwd: bad argument");
-  SCP_CHECK(((uintptr_t)slabs & 15) == 0 && slab_stride % 4 == 0, SCP_ERR_SHAPE,
-            "scp_enc_tail_fwd: slabs must be 16-byte aligned with a stride that is a multiple of 4");
-  SCP_CHECK((m->xhat1 == nullptr) == (m->rstd1 == nullptr) && (m->xhat2 == nullptr) == (m->rstd2 == nullptr) &&
-                (m->xhat1 == nullptr) == (m->xhat2 == nullptr),
-            SCP_ERR_ARG, "scp_enc_tail_fwd: the four saved-for-backward buffers go together");
-  const int grid = (m->B + ET_ROWS - 1) / ET_ROWS;
-#define ET_FWD(N)                                                                                                     \
-  case N:                                                                                                             \
-    hipLaunchKernelGGL(enc_tail_fwd_kernel<N>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, *m, slabs, slab_stride, \
-                       nslab, out, ldo);                                                                              \
+  TailSet S = {};
+  for (int b = 0; b < nbranch; b++) {
+    const ScpEncTail* m = ms + b;
+    SCP_CHECK(m->slabs && m->out && m->nslab > 0 && m->ldo >= (m->N3 > 0 ? m->N3 : m->H2) && m->ld_slab >= m->H1,
+              SCP_ERR_ARG, "scp_enc_tail_fwd: bad slab / output argument");
+    SCP_CHECK(((uintptr_t)m->slabs & 15) == 0 && m->slab_stride % 4 == 0 && m->ld_slab % 4 == 0, SCP_ERR_SHAPE,
+              "scp_enc_tail_fwd: slabs must be 16-byte aligned with strides that are multiples of 4");
+    SCP_CHECK((m->xhat1 == nullptr) == (m->rstd1 == nullptr) && (m->xhat2 == nullptr) == (m->rstd2 == nullptr) &&
+                  (m->xhat1 == nullptr) == (m->xhat2 == nullptr),
+              SCP_ERR_ARG, "scp_enc_tail_fwd: the four saved-for-backward buffers go together");
+    S.b[b] = *m;
+  }
+  const int nrec = (ms[0].B + ET_RW - 1) / ET_RW;
+  const dim3 grid((nrec + ET_WAVES - 1) / ET_WAVES, nbranch);
+#define ET_FWD(N)                                                                                          \
+  case N:                                                                                                  \
+    hipLaunchKernelGGL(enc_tail_fwd_kernel<N>, grid, dim3(64 * ET_WAVES), 0, (hipStream_t)stream_, S);     \
     break;
-  switch ((m->H1 + 127) / 128) { ET_FWD(1) ET_FWD(2) ET_FWD(3) ET_FWD(4) ET_FWD(5) ET_FWD(6) ET_FWD(7) ET_FWD(8) }
+  switch (tail_nch(ms, nbranch)) { ET_FWD(1) ET_FWD(2) ET_FWD(3) ET_FWD(4) }
 #undef ET_FWD
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
 
-extern "C" long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3) {
-  const TailOff off = tail_off(H1, H2, N3);
-  const long nblk = (B + ET_ROWS - 1) / ET_ROWS, nchunk = (B + ETW_ROWS - 1) / ETW_ROWS;
-  return nblk * off.pv + nchunk * (long)H2 * H1 + (long)B * H2 + 8;
-}
+extern "C" long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3) { return tail_ws(B, H1, H2, N3).total; }
 
-extern "C" int scp_enc_tail_bwd(const ScpEncTail* m, const float* dOut, long lddo, float* dY1, long ldy, float* ws,
-                                float* dg1, float* dbe1, float* db1, float* dW2, float* dg2, float* dbe2, float* db2,
-                                float* dW3, float* db3, void* stream_) {
+extern "C" int scp_enc_tail_bwd(const ScpEncTail* ms, int nbranch, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  int rc = tail_check(m, "scp_enc_tail_bwd");
+  int rc = tail_check(ms, nbranch, "scp_enc_tail_bwd");
   if (rc) return rc;
-  SCP_CHECK(dOut && dY1 && ws && m->xhat1 && m->rstd1 && m->xhat2 && m->rstd2, SCP_ERR_ARG, "scp_enc_tail_bwd: null pointer");
-  SCP_CHECK(ldy >= m->H1 && ldy % 4 == 0 && (((uintptr_t)dY1 | (uintptr_t)ws) & 15) == 0, SCP_ERR_SHAPE,
-            "scp_enc_tail_bwd: dY1 / ws must be 16-byte aligned, ldy %% 4 == 0");
-  SCP_CHECK(lddo >= (m->N3 > 0 ? m->N3 : m->H2), SCP_ERR_ARG, "scp_enc_tail_bwd: dOut leading dimension too small");
-  const TailOff off = tail_off(m->H1, m->H2, m->N3);
-  const int nblk = (m->B + ET_ROWS - 1) / ET_ROWS, nchunk = (m->B + ETW_ROWS - 1) / ETW_ROWS;
-  const long wn = (long)m->H2 * m->H1;
-  float* part = ws;
-  float* slab = part + (long)nblk * off.pv;        // pv % 4 == 0 keeps it 16-byte aligned
-  float* dz2 = slab + (long)nchunk * wn;
-#define ET_BWD(N)                                                                                                       \
-  case N:                                                                                                               \
-    hipLaunchKernelGGL(enc_tail_bwd_kernel<N>, dim3(nblk), dim3(256), 0, stream, *m, dOut, lddo, dY1, ldy, dz2, part);   \
+  TailSet S = {};
+  TailRedSet R = {};
+  int max_h1 = 0, any_w2 = 0;
+  long max_total = 0;
+  const int B = ms[0].B;
+  for (int b = 0; b < nbranch; b++) {
+    const ScpEncTail* m = ms + b;
+    SCP_CHECK(m->dOut && (m->dY1 || m->dYT) && m->ws && m->xhat1 && m->rstd1 && m->xhat2 && m->rstd2, SCP_ERR_ARG,
+              "scp_enc_tail_bwd: null pointer");
+    SCP_CHECK(!m->dY1 || (m->ldy >= m->H1 && m->ldy % 4 == 0 && ((uintptr_t)m->dY1 & 15) == 0), SCP_ERR_SHAPE,
+              "scp_enc_tail_bwd: dY1 must be 16-byte aligned, ldy %% 4 == 0");
+    SCP_CHECK(!m->dYT || (m->ldt % 4 == 0 && m->ldt >= (B + 63) / 64 * 64 && ((uintptr_t)m->dYT & 7) == 0), SCP_ERR_SHAPE,
+              "scp_enc_tail_bwd: dYT needs an 8-byte aligned base, ldt %% 4 == 0 and ldt >= cells rounded up to 64");
+    SCP_CHECK(((uintptr_t)m->ws & 15) == 0, SCP_ERR_SHAPE, "scp_enc_tail_bwd: ws must be 16-byte aligned");
+    SCP_CHECK(m->lddo >= (m->N3 > 0 ? m->N3 : m->H2), SCP_ERR_ARG, "scp_enc_tail_bwd: dOut leading dimension too small");
+    S.b[b] = *m;
+    const TailOff off = tail_off(m->H1, m->H2, m->N3);
+    const TailWs w = tail_ws(B, m->H1, m->H2, m->N3);
+    TailRed& r = R.b[b];
+    r.part = m->ws; r.nblk = w.nrec; r.pv = off.pv; r.slab = m->ws + w.o_slab; r.nchunk = w.nchunk; r.wn = w.wn;
+    r.dW2 = m->dW2;
+    const int begs[8] = {off.g1, off.be1, off.b1, off.g2, off.be2, off.b2, off.w3, off.b3};
+    const int ends[8] = {off.be1, off.b1, off.g2, off.be2, off.b2, off.w3, off.b3, off.b3 + m->N3};
+    float* dsts[8] = {m->dg1, m->dbe1, m->db1, m->dg2, m->dbe2, m->db2, m->dW3, m->db3};
+    for (int q = 0; q < 8; q++) { r.seg_beg[q] = begs[q]; r.seg_end[q] = ends[q]; r.seg_dst[q] = dsts[q]; }
+    max_h1 = m->H1 > max_h1 ? m->H1 : max_h1;
+    any_w2 |= m->dW2 != nullptr;
+    const long total = off.pv + w.wn;
+    max_total = total > max_total ? total : max_total;
+  }
+  const int nrec = (B + ET_RW - 1) / ET_RW, nchunk = (B + ETW_ROWS - 1) / ETW_ROWS;
+  const dim3 grid((nrec + ET_WAVES - 1) / ET_WAVES, nbranch);
+  for (int b = 0; b < nbranch; b++)               // cells past the batch end of the padded transposed copy read as 0
+    if (ms[b].dYT && B % 64) {
+      SCP_HIP(hipMemsetAsync(ms[b].dYT, 0, (size_t)ms[b].H1 * ms[b].ldt * sizeof(__bf16), stream));
+    }
+#define ET_BWD(N)                                                                              \
+  case N:                                                                                      \
+    hipLaunchKernelGGL(enc_tail_bwd_kernel<N>, grid, dim3(64 * ET_WAVES), 0, stream, S);       \
     break;
-  switch ((m->H1 + 127) / 128) { ET_BWD(1) ET_BWD(2) ET_BWD(3) ET_BWD(4) ET_BWD(5) ET_BWD(6) ET_BWD(7) ET_BWD(8) }
+  switch (tail_nch(ms, nbranch)) { ET_BWD(1) ET_BWD(2) ET_BWD(3) ET_BWD(4) }
 #undef ET_BWD
   SCP_LAUNCH_CHECK();
-  if (dW2) {
-    hipLaunchKernelGGL(enc_tail_w2_kernel, dim3((m->H1 + 127) / 128, nchunk), dim3(256), 0, stream, *m, dz2, slab);
+  if (any_w2) {
+    hipLaunchKernelGGL(enc_tail_w2_kernel, dim3((max_h1 + 127) / 128, nchunk, nbranch), dim3(256), 0, stream, S);
     SCP_LAUNCH_CHECK();
   }
-  TailRed r = {};
-  r.part = part; r.nblk = nblk; r.pv = off.pv; r.slab = slab; r.nchunk = nchunk; r.wn = wn; r.dW2 = dW2;
-  const int begs[8] = {off.g1, off.be1, off.b1, off.g2, off.be2, off.b2, off.w3, off.b3};
-  const int ends[8] = {off.be1, off.b1, off.g2, off.be2, off.b2, off.w3, off.b3, off.b3 + m->N3};
-  float* dsts[8] = {dg1, dbe1, db1, dg2, dbe2, db2, dW3, db3};
-  r.nseg = 8;
-  for (int q = 0; q < 8; q++) { r.seg_beg[q] = begs[q]; r.seg_end[q] = ends[q]; r.seg_dst[q] = dsts[q]; }
-  const long total = off.pv + wn;
-  hipLaunchKernelGGL(enc_tail_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, r);
+  hipLaunchKernelGGL(enc_tail_reduce_kernel, dim3((unsigned)((max_total + 63) / 64), nbranch), dim3(256), 0, stream, R);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

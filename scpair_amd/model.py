@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from . import ops
 from .loss import binarized_loss, raw_loss, scaled_loss
 from .sparse import BatchTiles, DeviceCSR
-from .utils import (FCNN, HipLinear, add_weight_decay, encoder_branch, eval_net, evaluating_mode, init_weights,
+from .utils import (FCNN, HipLinear, add_weight_decay, encoder_branches, eval_net, evaluating_mode, init_weights,
                     set_seed, train_net, training_mode)
 
 
@@ -84,13 +84,11 @@ class Input_Module(nn.Module):
                                             HipLinear(hidden_layer[-1], 1, bias=True))
 
     def forward(self, input, input_batch):
-        latent_rep = encoder_branch(self.hidden_rep, self.extra_linear_rep if self.add_linear_layer is True else None,
-                                    input, input_batch)
+        branches = [(self.hidden_rep, self.extra_linear_rep if self.add_linear_layer is True else None)]
         if self.infer_library_size == True:  # noqa: E712
-            latent_lib = encoder_branch(self.hidden_lib[0], self.hidden_lib[1], input, input_batch)
-        else:
-            latent_lib = None
-        return latent_rep, latent_lib
+            branches.append((self.hidden_lib[0], self.hidden_lib[1]))
+        outs = encoder_branches(branches, input, input_batch)
+        return outs[0], (outs[1] if len(outs) > 1 else None)
 
 
 class Output_Module_Ber(nn.Module):

@@ -13,7 +13,9 @@ import torch
 from . import _lib
 from .sparse import BatchTiles
 
-_cfg = {"ns": 3, "seed_ctr": 0, "fused_timer": None}
+import os as _os
+
+_cfg = {"ns": 3, "seed_ctr": 0, "fused_timer": None, "fwd_wgs": int(_os.environ.get("SCPAIR_FWD_WGS", "256"))}
 
 
 def set_precision(mode: str):
@@ -104,8 +106,16 @@ def shadow_of(W, create=True):
     L = _lib.lib()
     H, cols = W.shape
     ld = (cols + 7) // 8 * 8
-    sh = ent[0] if (ent is not None and ent[0].shape == (H, ld) and ent[0].device == W.device) else \
-        torch.empty((H, ld), dtype=torch.bfloat16, device=W.device)
+    if ent is not None and ent[0].shape == (H, ld) and ent[0].device == W.device:
+        sh = ent[0]
+    else:
+        pk, off = _pack_of(W)
+        if pk is not None and pk[2].device == W.device:   # packed pair: adjacent row blocks of one shadow
+            if pk[3]["shadow"] is None or pk[3]["shadow"].shape != (pk[2].shape[0], ld) or pk[3]["shadow"].device != W.device:
+                pk[3]["shadow"] = torch.empty((pk[2].shape[0], ld), dtype=torch.bfloat16, device=W.device)
+            sh = pk[3]["shadow"][off:off + H]
+        else:
+            sh = torch.empty((H, ld), dtype=torch.bfloat16, device=W.device)
     Wc = W.detach()
     if not Wc.is_contiguous():
         raise RuntimeError("first-layer weights must be contiguous")
@@ -405,10 +415,83 @@ def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------
-# Whole encoder branch on a sparse minibatch: first layer on the tile list + the fused tail (enc_tail.hip)
+# Whole encoder on a sparse minibatch: first-layer product(s) on the tile list + the fused tail (enc_tail.hip)
 #   x -> Linear(F, H1) -> LN -> act -> Dropout -> Linear(H1, H2) -> LN -> act -> Dropout [-> Linear(H2, N3)]
-# (Input_Module.hidden_rep + extra_linear_rep, hidden_lib + its head: model.py:77-92, 124-143)
+# for one or two branches (Input_Module.hidden_rep + extra_linear_rep, hidden_lib + its head: model.py:77-92, 124-143).
+# Two branches whose first-layer weights are packed (pack_first_layers) run their first-layer product, its weight
+# gradient and the AdamW step as ONE launch each over the [H1a + H1b, F] weight block.
 # ------------------------------------------------------------------------------------------------
+_packs = {}            # id(Wa) -> (weakref(Wa), weakref(Wb), cat, {"shadow": bf16 [Ha+Hb, ld] or None})
+
+
+def _pack_of(W):
+    """(pack entry, row offset) of a first-layer weight that is one of a packed pair, else (None, 0)."""
+    for ent in _packs.values():
+        a, b = ent[0](), ent[1]()
+        if a is W:
+            return ent, 0
+        if b is W and a is not None:
+            return ent, a.shape[0]
+    return None, 0
+
+
+def _rows_adjacent(a, b, row_bytes):
+    return b.data_ptr() == a.data_ptr() + a.shape[0] * row_bytes
+
+
+def pack_first_layers(Wa, Wb):
+    """Make two first-layer weights of the same input (fp32, [Ha, F] and [Hb, F], on the GPU) adjacent row blocks of one
+    [Ha + Hb, F] tensor (their .data become views of it; values, shapes and Parameter identity are unchanged), so the
+    bf16 first-layer kernels treat the two branches as one layer.  Idempotent; returns False when the pair cannot be
+    packed.  Optimiser state and bf16 shadows created afterwards are packed the same way."""
+    if Wa is Wb or Wa.ndim != 2 or Wb.ndim != 2 or Wa.shape[1] != Wb.shape[1] or not (Wa.is_cuda and Wb.is_cuda) \
+            or Wa.device != Wb.device or Wa.dtype != torch.float32 or Wb.dtype != torch.float32 \
+            or (Wa.shape[0] * Wa.shape[1]) % 4 or not (Wa.is_contiguous() and Wb.is_contiguous()):
+        return False
+    F = Wa.shape[1]
+    ent = _packs.get(id(Wa))
+    if ent is not None and ent[0]() is Wa and ent[1]() is Wb and _rows_adjacent(Wa, Wb, 4 * F) \
+            and Wa.data_ptr() == ent[2].data_ptr():
+        return True
+    for k in [k for k, v in _packs.items() if v[0]() is None or v[1]() is None]:
+        del _packs[k]
+    Ha, Hb = Wa.shape[0], Wb.shape[0]
+    with torch.no_grad():
+        cat = torch.empty((Ha + Hb, F), dtype=torch.float32, device=Wa.device)
+        cat[:Ha].copy_(Wa)
+        cat[Ha:].copy_(Wb)
+        Wa.data = cat[:Ha]
+        Wb.data = cat[Ha:]
+    _shadows.pop(id(Wa), None)
+    _shadows.pop(id(Wb), None)
+    _packs[id(Wa)] = (weakref.ref(Wa), weakref.ref(Wb), cat, {"shadow": None})
+    return True
+
+
+def _new_adam_state(opt, p):
+    """Fresh AdamW state of p; the two weights of a packed pair get adjacent moments (one [Ha+Hb, F] block each)."""
+    ent, off = _pack_of(p)
+    if ent is not None:
+        a, b = ent[0](), ent[1]()
+        if a is not None and b is not None and len(opt.state[a]) == 0 and len(opt.state[b]) == 0 \
+                and _rows_adjacent(a, b, 4 * a.shape[1]):
+            m = torch.zeros((a.shape[0] + b.shape[0], a.shape[1]), dtype=torch.float32, device=a.device)
+            v = torch.zeros_like(m)
+            for q, lo in ((a, 0), (b, a.shape[0])):
+                st = opt.state[q]
+                st["step"] = 0
+                st["exp_avg"] = m[lo:lo + q.shape[0]]
+                st["exp_avg_sq"] = v[lo:lo + q.shape[0]]
+            return
+    st = opt.state[p]
+    st["step"] = 0
+    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+
+ENC_MAX_BRANCHES = 4
+
+
 def enc_branch_supported(x, cov, W1, W2, W3, ln1, ln2):
     """The fused path covers the reference's default encoder shape: sparse minibatch, no covariate block, two FCNN
     layers with LayerNorm, hidden widths H1 % 4 == 0, H1 <= 1024, H2 <= 64, final Linear with N3 <= 64 outputs."""
@@ -421,135 +504,273 @@ def enc_branch_supported(x, cov, W1, W2, W3, ln1, ln2):
                for t in (W1, W2, W3))
 
 
-class EncBranchFn(torch.autograd.Function):
+def _carve(sizes, dev):
+    """One allocation cut into float32 pieces of the given sizes, each 16-byte aligned."""
+    offs, o = [], 0
+    for n_ in sizes:
+        offs.append(o)
+        o += (n_ + 3) // 4 * 4
+    buf = torch.empty(o + 4, dtype=torch.float32, device=dev)
+    return buf, [buf[a:a + n_] for a, n_ in zip(offs, sizes)]
+
+
+class EncBranchesFn(torch.autograd.Function):
+    """cfg: dict(slope, br=[dict(p1, p2, seed1, seed2, eps1, eps2, shadow, fused, sink)] per branch);
+    tensors: W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 per branch.  Returns one output per branch."""
+
     @staticmethod
-    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, slope, p1, p2, seed1, seed2, eps1, eps2, shadow,
-                fused, sink):
+    def forward(ctx, x, cfg, *tensors):
         L = _lib.lib()
+        nb = len(cfg["br"])
+        P = [tensors[10 * i:10 * i + 10] for i in range(nb)]
         Bn, F = x.shape
-        H1, H2 = W1.shape[0], W2.shape[0]
-        N3 = 0 if W3 is None else W3.shape[0]
-        if W1.shape[1] != F:
-            raise ValueError(f"encoder: first layer expects {W1.shape[1]} inputs, the minibatch has {F} features")
+        dev = P[0][0].device
         ns = _ns()
-        dev = W1.device
-        use_bf = ns == 1 and shadow is not None
-        if use_bf:
-            tiles_ = ((Bn + 255) // 256) * ((H1 + 127) // 128)
-            nsplit = max(1, min(512 // max(tiles_, 1), ((F + 63) // 64) // 4, 16), L.scp_spmm_fwd_bf16_min_split(F))
-        else:
-            nsplit = _pick_split(Bn, H1, F)
-        nsplit = L.scp_gemm_split_count(F, nsplit)
+        H1s = [p_[0].shape[0] for p_ in P]
+        H2s = [p_[4].shape[0] for p_ in P]
+        N3s = [0 if p_[8] is None else p_[8].shape[0] for p_ in P]
+        for p_ in P:
+            if p_[0].shape[1] != F:
+                raise ValueError(f"encoder: first layer expects {p_[0].shape[1]} inputs, the minibatch has {F} features")
+        shadows = [b_["shadow"] for b_ in cfg["br"]]
+        use_bf = ns == 1 and all(sh is not None for sh in shadows)
+        # one first-layer launch for both branches when their weights (and bf16 shadows) are adjacent row blocks
+        merged = (nb == 2 and use_bf and _rows_adjacent(P[0][0], P[1][0], 4 * F)
+                  and shadows[0].shape[1] == shadows[1].shape[1]
+                  and _rows_adjacent(shadows[0], shadows[1], 2 * shadows[0].shape[1]))
+        groups = [list(range(nb))] if merged else [[i] for i in range(nb)]
         train = any(ctx.needs_input_grad)
-        nout = N3 if N3 > 0 else H2
-        # one allocation: slabs | out | (xhat1 | rstd1 | xhat2 | rstd2)
-        n_slab, n_out = nsplit * Bn * H1, Bn * nout
-        n_save = (Bn * H1 + Bn + Bn * H2 + Bn + 12) if train else 0
-        buf = torch.empty(n_slab + n_out + n_save + 8, dtype=torch.float32, device=dev)
-        slabs = buf[:n_slab]
-        if use_bf:
-            _lib.check(L.scp_spmm_fwd_bf16(Bn, H1, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val),
-                                           shadow.data_ptr(), shadow.shape[1], slabs.data_ptr(), H1, nsplit,
-                                           _lib.stream()), "scp_spmm_fwd_bf16")
-        else:
-            _lib.check(L.scp_spmm_fwd(Bn, H1, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(),
-                                      F, slabs.data_ptr(), H1, None, nsplit, ns, _lib.stream()), "scp_spmm_fwd")
-        o0 = (n_slab + 3) // 4 * 4
-        out = buf[o0:o0 + n_out].view(Bn, nout)
-        xhat1 = rstd1 = xhat2 = rstd2 = None
+        nouts = [n3 if n3 > 0 else h2 for n3, h2 in zip(N3s, H2s)]
+        # one allocation: slabs of every first-layer launch | outputs | saved-for-backward pieces
+        nsplits, slab_sizes = [], []
+        for g in groups:
+            Hg = sum(H1s[i] for i in g)
+            if use_bf:
+                tiles_ = ((Bn + 255) // 256) * ((Hg + 127) // 128)
+                nsp = max(1, min(_cfg.get("fwd_wgs", 512) // max(tiles_, 1), ((F + 63) // 64) // 4, 16), L.scp_spmm_fwd_bf16_min_split(F))
+            else:
+                nsp = _pick_split(Bn, Hg, F)
+            nsp = L.scp_gemm_split_count(F, nsp)
+            nsplits.append(nsp)
+            slab_sizes.append(nsp * Bn * Hg)
+        sizes = list(slab_sizes) + [Bn * n for n in nouts]
         if train:
-            o1 = (o0 + n_out + 3) // 4 * 4
-            xhat1 = buf[o1:o1 + Bn * H1]
-            o2 = o1 + Bn * H1
-            rstd1 = buf[o2:o2 + Bn]
-            o3 = (o2 + Bn + 3) // 4 * 4
-            xhat2 = buf[o3:o3 + Bn * H2]
-            rstd2 = buf[o3 + Bn * H2:o3 + Bn * H2 + Bn]
-        seed_dev = _seed_dev() if (p1 > 0 or p2 > 0) else None
-        m = _lib.EncTail(Bn, H1, H2, N3, _lib.ptr(b1), g1.data_ptr(), be1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
-                         g2.data_ptr(), be2.data_ptr(), _lib.ptr(W3), _lib.ptr(b3), eps1, eps2, slope, p1, p2, seed1, seed2,
-                         seed_dev, _lib.ptr(xhat1), _lib.ptr(rstd1), _lib.ptr(xhat2), _lib.ptr(rstd2))
-        _lib.check(L.scp_enc_tail_fwd(C.byref(m), slabs.data_ptr(), Bn * H1, nsplit, out.data_ptr(), nout, _lib.stream()),
-                   "scp_enc_tail_fwd")
+            for i in range(nb):
+                sizes += [Bn * H1s[i], Bn, Bn * H2s[i], Bn]
+        buf, pieces = _carve(sizes, dev)
+        slabs = pieces[:len(groups)]
+        outs = [pieces[len(groups) + i].view(Bn, nouts[i]) for i in range(nb)]
+        saves = [pieces[len(groups) + nb + 4 * i:len(groups) + nb + 4 * i + 4] if train else (None,) * 4 for i in range(nb)]
+        stream = _lib.stream()
+        slab_of = {}
+        for gi, g in enumerate(groups):
+            Hg = sum(H1s[i] for i in g)
+            W1 = P[g[0]][0]
+            if use_bf:
+                sh = shadows[g[0]]
+                _lib.check(L.scp_spmm_fwd_bf16(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), sh.data_ptr(),
+                                               sh.shape[1], slabs[gi].data_ptr(), Hg, nsplits[gi], stream),
+                           "scp_spmm_fwd_bf16")
+            else:
+                _lib.check(L.scp_spmm_fwd(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(), F,
+                                          slabs[gi].data_ptr(), Hg, None, nsplits[gi], ns, stream), "scp_spmm_fwd")
+            col = 0
+            for i in g:
+                slab_of[i] = (slabs[gi].data_ptr() + 4 * col, Bn * Hg, Hg, nsplits[gi])
+                col += H1s[i]
+        any_drop = any(b_["p1"] > 0 or b_["p2"] > 0 for b_ in cfg["br"])
+        seed_dev = _seed_dev() if any_drop else None
+        arr = (_lib.EncTail * nb)()
+        for i in range(nb):
+            W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 = P[i]
+            c = cfg["br"][i]
+            m = arr[i]
+            m.B, m.H1, m.H2, m.N3 = Bn, H1s[i], H2s[i], N3s[i]
+            m.b1, m.g1, m.be1 = _lib.ptr(b1), g1.data_ptr(), be1.data_ptr()
+            m.W2, m.b2, m.g2, m.be2 = W2.data_ptr(), b2.data_ptr(), g2.data_ptr(), be2.data_ptr()
+            m.W3, m.b3 = _lib.ptr(W3), _lib.ptr(b3)
+            m.eps1, m.eps2, m.slope, m.p1, m.p2 = c["eps1"], c["eps2"], cfg["slope"], c["p1"], c["p2"]
+            m.seed1, m.seed2, m.seed_dev = c["seed1"], c["seed2"], seed_dev
+            xh1, r1, xh2, r2 = saves[i]
+            m.xhat1, m.rstd1, m.xhat2, m.rstd2 = _lib.ptr(xh1), _lib.ptr(r1), _lib.ptr(xh2), _lib.ptr(r2)
+            m.slabs, m.slab_stride, m.ld_slab, m.nslab = slab_of[i]
+            m.out, m.ldo = outs[i].data_ptr(), nouts[i]
+        _lib.check(L.scp_enc_tail_fwd(arr, nb, stream), "scp_enc_tail_fwd")
         if train:
-            ctx.m, ctx.tiles, ctx.buf = m, x, buf
-            ctx.save_for_backward(W1, b1, g1, be1, W2, b2, g2, be2, W3, b3)
-            ctx.dims = (Bn, F, H1, H2, N3, ns, use_bf)
-            ctx.fused = fused if (use_bf and F % 4 == 0) else None
-            ctx.sink = sink if (use_bf and ctx.fused is None) else None
-        return out
+            ctx.arr, ctx.tiles, ctx.buf, ctx.cfg = arr, x, buf, cfg
+            ctx.save_for_backward(*[t for t in tensors if t is not None])
+            ctx.present = [t is not None for t in tensors]
+            ctx.dims = (Bn, F, H1s, H2s, N3s, ns, use_bf, groups)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         L = _lib.lib()
-        W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 = ctx.saved_tensors
-        Bn, F, H1, H2, N3, ns, use_bf = ctx.dims
-        dev = W1.device
-        dout = _f32c(dout)
-        t = ctx.tiles
-        # one allocation for every small gradient and the workspace: dg1 dbe1 db1 | dg2 dbe2 db2 | dW3 db3 | dW2 | dY1 | ws
-        nws = L.scp_enc_tail_ws_floats(Bn, H1, H2, N3)
-        sizes = [H1, H1, H1, H2, H2, H2, N3 * H2, N3, H2 * H1, Bn * H1, nws]
-        offs, o = [], 0
-        for n_ in sizes:
-            offs.append(o)
-            o += (n_ + 3) // 4 * 4
-        gb = torch.empty(o + 4, dtype=torch.float32, device=dev)
-        dg1, dbe1, db1, dg2, dbe2, db2, dW3, db3, dW2, dY1, ws = [gb[a:a + n_] for a, n_ in zip(offs, sizes)]
-        _lib.check(L.scp_enc_tail_bwd(C.byref(ctx.m), dout.data_ptr(), dout.shape[1], dY1.data_ptr(), H1, ws.data_ptr(),
-                                      dg1.data_ptr(), dbe1.data_ptr(), _lib.ptr(db1 if b1 is not None else None),
-                                      dW2.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr(),
-                                      _lib.ptr(dW3 if N3 else None), _lib.ptr(db3 if N3 else None), _lib.stream()),
-                   "scp_enc_tail_bwd")
-        dW1 = None
-        if ctx.needs_input_grad[1]:
+        it = iter(ctx.saved_tensors)
+        tensors = [next(it) if pr else None for pr in ctx.present]
+        Bn, F, H1s, H2s, N3s, ns, use_bf, groups = ctx.dims
+        nb = len(H1s)
+        P = [tensors[10 * i:10 * i + 10] for i in range(nb)]
+        cfg, arr, t = ctx.cfg, ctx.arr, ctx.tiles
+        dev = P[0][0].device
+        stream = _lib.stream()
+        ldt = (Bn + 63) // 64 * 64
+        # one allocation for every small gradient and the workspaces; the first-layer gradient operand separately
+        sizes = []
+        for i in range(nb):
+            nws = L.scp_enc_tail_ws_floats(Bn, H1s[i], H2s[i], N3s[i])
+            sizes += [H1s[i], H1s[i], H1s[i], H2s[i], H2s[i], H2s[i], N3s[i] * H2s[i], N3s[i], H2s[i] * H1s[i], nws,
+                      0 if use_bf else Bn * H1s[i]]
+        gb, pieces = _carve(sizes, dev)
+        need_w1 = [ctx.needs_input_grad[2 + 10 * i] for i in range(nb)]
+        dYT = {}
+        if use_bf:
+            for g in groups:
+                Hg = sum(H1s[i] for i in g)
+                tbuf = torch.empty((Hg, ldt), dtype=torch.bfloat16, device=dev)
+                row = 0
+                for i in g:
+                    dYT[i] = (tbuf, row)
+                    row += H1s[i]
+        keep = []
+        grads = []
+        for i in range(nb):
+            dg1, dbe1, db1, dg2, dbe2, db2, dW3, db3, dW2, ws, dY1 = pieces[11 * i:11 * i + 11]
+            W1, b1 = P[i][0], P[i][1]
+            nout = N3s[i] if N3s[i] else H2s[i]
+            do = douts[i]
+            do = torch.zeros((Bn, nout), dtype=torch.float32, device=dev) if do is None else _f32c(do)
+            keep.append(do)
+            m = arr[i]
+            m.dOut, m.lddo = do.data_ptr(), do.shape[1]
+            m.dY1, m.ldy = (None, 0) if use_bf else (dY1.data_ptr(), H1s[i])
             if use_bf:
-                ldt = (Bn + 63) // 64 * 64
-                dYT = torch.empty((H1, ldt), dtype=torch.bfloat16, device=dev)
-                _lib.check(L.scp_transpose_bf16(dY1.data_ptr(), Bn, H1, H1, dYT.data_ptr(), ldt, _lib.stream()),
-                           "scp_transpose_bf16")
-                if ctx.fused is not None:
-                    m_, v_, sh_, hp = ctx.fused.begin_step(W1)
-                    tm = _cfg["fused_timer"]
-                    if tm is not None:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                    _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, H1, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
-                                                        dYT.data_ptr(), ldt, W1.data_ptr(), F, m_.data_ptr(),
-                                                        v_.data_ptr(), sh_.data_ptr(), sh_.shape[1], *hp,
-                                                        _lib.stream()), "scp_spmm_dw_adamw_bf16")
-                    if tm is not None:
-                        e1.record()
-                        tm.append((e0, e1, H1 * F, int(t.nnz) * (8 if t.val is not None else 4) + 2 * H1 * ldt))
-                elif ctx.sink is not None:
-                    _lib.check(L.scp_spmm_dw_bf16_g16(Bn, H1, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
-                                                      dYT.data_ptr(), ldt, ctx.sink.view.data_ptr(), F,
-                                                      _lib.stream()), "scp_spmm_dw_bf16_g16")
-                    ctx.sink.written = True
-                else:
-                    dW1 = torch.empty((H1, F), dtype=torch.float32, device=dev)
-                    _lib.check(L.scp_spmm_dw_bf16(Bn, H1, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
-                                                  dYT.data_ptr(), ldt, dW1.data_ptr(), F, _lib.stream()),
-                               "scp_spmm_dw_bf16")
+                tbuf, row = dYT[i]
+                m.dYT, m.ldt = tbuf.data_ptr() + 2 * row * ldt, ldt
             else:
-                dW1 = torch.empty((H1, F), dtype=torch.float32, device=dev)
-                _lib.check(L.scp_spmm_dw(Bn, H1, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), dY1.data_ptr(), H1,
-                                         dW1.data_ptr(), F, ns, _lib.stream()), "scp_spmm_dw")
-        ctx.buf = ctx.tiles = None
-        return (None, dW1, db1 if b1 is not None else None, dg1, dbe1, dW2.view(H2, H1), db2, dg2, dbe2,
-                dW3.view(N3, H2) if N3 else None, db3 if N3 else None) + (None,) * 10
+                m.dYT, m.ldt = None, 0
+            m.ws = ws.data_ptr()
+            m.dg1, m.dbe1, m.db1 = dg1.data_ptr(), dbe1.data_ptr(), _lib.ptr(db1 if b1 is not None else None)
+            m.dW2, m.dg2, m.dbe2, m.db2 = dW2.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr()
+            m.dW3, m.db3 = _lib.ptr(dW3 if N3s[i] else None), _lib.ptr(db3 if N3s[i] else None)
+            grads.append([None, db1 if b1 is not None else None, dg1, dbe1, dW2.view(H2s[i], H1s[i]), db2, dg2, dbe2,
+                          dW3.view(N3s[i], H2s[i]) if N3s[i] else None, db3 if N3s[i] else None])
+        _lib.check(L.scp_enc_tail_bwd(arr, nb, stream), "scp_enc_tail_bwd")
+        # ---- first-layer weight gradient (and, where registered, the AdamW step in its epilogue) -------------------
+        tp, tk, tv = _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val)
+        if not use_bf:
+            for i in range(nb):
+                if need_w1[i]:
+                    dW1 = torch.empty((H1s[i], F), dtype=torch.float32, device=dev)
+                    _lib.check(L.scp_spmm_dw(Bn, H1s[i], F, tp, tk, tv, arr[i].dY1, H1s[i], dW1.data_ptr(), F, ns, stream),
+                               "scp_spmm_dw")
+                    grads[i][0] = dW1
+        else:
+            for g in groups:
+                if not any(need_w1[i] for i in g):
+                    continue
+                units = [g]
+                if len(g) == 2:
+                    fz = [cfg["br"][i]["fused"] if F % 4 == 0 else None for i in g]
+                    sk = [cfg["br"][i]["sink"] for i in g]
+                    if fz[0] is not None and fz[1] is not None:
+                        if not _fused_pair_ok(fz[0], fz[1], P[g[0]][0], P[g[1]][0]):
+                            units = [[g[0]], [g[1]]]
+                    elif fz[0] is not None or fz[1] is not None or (sk[0] is None) != (sk[1] is None) \
+                            or (sk[0] is not None and not _rows_adjacent(sk[0].view, sk[1].view, 2 * F)) \
+                            or not all(need_w1[i] for i in g):
+                        units = [[g[0]], [g[1]]]
+                for u in units:
+                    if not need_w1[u[0]]:
+                        continue
+                    Hu = sum(H1s[i] for i in u)
+                    tbuf, row = dYT[u[0]]
+                    dyt_ptr = tbuf.data_ptr() + 2 * row * ldt
+                    W1 = P[u[0]][0]
+                    fz = cfg["br"][u[0]]["fused"] if F % 4 == 0 else None
+                    sk = cfg["br"][u[0]]["sink"] if fz is None else None
+                    if fz is not None:
+                        m_, v_, sh_, hp = fz.begin_step(W1)
+                        for i in u[1:]:
+                            cfg["br"][i]["fused"].begin_step(P[i][0])
+                        tm = _cfg["fused_timer"]
+                        if tm is not None:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                        _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, Hu, F, tp, tk, tv, dyt_ptr, ldt, W1.data_ptr(), F,
+                                                            m_.data_ptr(), v_.data_ptr(), sh_.data_ptr(), sh_.shape[1],
+                                                            *hp, stream), "scp_spmm_dw_adamw_bf16")
+                        if tm is not None:
+                            e1.record()
+                            tm.append((e0, e1, Hu * F, int(t.nnz) * (8 if t.val is not None else 4) + 2 * Hu * ldt))
+                    elif sk is not None:
+                        _lib.check(L.scp_spmm_dw_bf16_g16(Bn, Hu, F, tp, tk, tv, dyt_ptr, ldt, sk.view.data_ptr(), F, stream),
+                                   "scp_spmm_dw_bf16_g16")
+                        for i in u:
+                            cfg["br"][i]["sink"].written = True
+                    else:
+                        dW = torch.empty((Hu, F), dtype=torch.float32, device=dev)
+                        _lib.check(L.scp_spmm_dw_bf16(Bn, Hu, F, tp, tk, tv, dyt_ptr, ldt, dW.data_ptr(), F, stream),
+                                   "scp_spmm_dw_bf16")
+                        row_ = 0
+                        for i in u:
+                            grads[i][0] = dW[row_:row_ + H1s[i]]
+                            row_ += H1s[i]
+        ctx.buf = ctx.tiles = ctx.arr = None
+        flat = [None, None]
+        for i in range(nb):
+            flat += grads[i]
+        return tuple(flat)
 
 
-def enc_branch(x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, slope, p1=0.0, p2=0.0, eps1=1e-5, eps2=1e-5):
-    shadow = fused = sink = None
-    if _ns() == 1:
-        shadow = shadow_of(W1)
-        if torch.is_grad_enabled() and W1.requires_grad:
-            fused = fused_handle(W1)
-            sink = grad_sink_of(W1) if fused is None else None
-    return EncBranchFn.apply(x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, float(slope), float(p1), float(p2),
-                             next_seed() if p1 > 0 else 0, next_seed() if p2 > 0 else 0, float(eps1), float(eps2),
-                             shadow, fused, sink)
+def _fused_pair_ok(fa, fb, Wa, Wb):
+    """Both weights of a packed pair are stepped by the same optimiser with the same hyper-parameters and step count,
+    and their moments and bf16 shadows are adjacent row blocks: one fused weight-gradient + AdamW launch covers both."""
+    pa, pb, opt = fa.param, fb.param, fa.opt
+    if pa is None or pb is None or opt is None or fb.opt is not opt or fa.group is not fb.group:
+        return False
+    if len(opt.state[pa]) == 0 and len(opt.state[pb]) == 0:
+        _new_adam_state(opt, pa)
+    sa, sb = opt.state[pa], opt.state[pb]
+    if len(sa) == 0 or len(sb) == 0 or sa["step"] != sb["step"]:
+        return False
+    F = Wa.shape[1]
+    sha, shb = shadow_of(pa), shadow_of(pb)
+    return (_rows_adjacent(sa["exp_avg"], sb["exp_avg"], 4 * F) and _rows_adjacent(sa["exp_avg_sq"], sb["exp_avg_sq"], 4 * F)
+            and sha.shape[1] == shb.shape[1] and _rows_adjacent(sha, shb, 2 * sha.shape[1]))
+
+
+def enc_branches(x, branches, slope, seeds=None):
+    """branches: list of dicts with W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 (W3 / b3 / b1 may be None) and optional
+    p1, p2, eps1, eps2.  seeds: optional list of (seed1, seed2) per branch (tests); drawn from next_seed() otherwise.
+    Returns the list of branch outputs."""
+    if not 1 <= len(branches) <= ENC_MAX_BRANCHES:
+        raise ValueError("enc_branches: 1..%d branches" % ENC_MAX_BRANCHES)
+    cfg = {"slope": float(slope), "br": []}
+    tensors = []
+    grad_on = torch.is_grad_enabled()
+    for i, b in enumerate(branches):
+        W1 = b["W1"]
+        p1, p2 = float(b.get("p1", 0.0)), float(b.get("p2", 0.0))
+        shadow = fused = sink = None
+        if _ns() == 1:
+            shadow = shadow_of(W1)
+            if grad_on and W1.requires_grad:
+                fused = fused_handle(W1)
+                sink = grad_sink_of(W1) if fused is None else None
+        if seeds is not None:
+            s1, s2 = seeds[i]
+        else:
+            s1, s2 = (next_seed() if p1 > 0 else 0), (next_seed() if p2 > 0 else 0)
+        cfg["br"].append(dict(p1=p1, p2=p2, seed1=int(s1), seed2=int(s2), eps1=float(b.get("eps1", 1e-5)),
+                              eps2=float(b.get("eps2", 1e-5)), shadow=shadow, fused=fused, sink=sink))
+        tensors += [W1, b.get("b1"), b["g1"], b["be1"], b["W2"], b["b2"], b["g2"], b["be2"], b.get("W3"), b.get("b3")]
+    return list(EncBranchesFn.apply(x, cfg, *tensors))
+
+
+def enc_branch(x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, slope, p1=0.0, p2=0.0, eps1=1e-5, eps2=1e-5, seeds=None):
+    return enc_branches(x, [dict(W1=W1, b1=b1, g1=g1, be1=be1, W2=W2, b2=b2, g2=g2, be2=be2, W3=W3, b3=b3, p1=p1, p2=p2,
+                                 eps1=eps1, eps2=eps2)], slope, None if seeds is None else [seeds])[0]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -613,9 +834,33 @@ def _dec_ws(B, F, K, dev):
     return ws_f, ws_d
 
 
+_ones = {}
+
+
+def backward_root(loss):
+    """loss.backward() for a scalar loss that IS the root of the step (the trainers' case): the fused decoder losses
+    take the upstream gradient to be exactly 1, so neither the ones tensor autograd would create nor the
+    multiplication of their stored gradients by it is launched."""
+    one = _ones.get(loss.device)
+    if one is None:
+        one = _ones[loss.device] = torch.ones((), dtype=torch.float32, device=loss.device)
+    if loss.dtype != torch.float32 or loss.ndim != 0:
+        loss.backward()
+        return
+    _cfg["root_loss"] = loss
+    try:
+        loss.backward(one)
+    finally:
+        _cfg["root_loss"] = None
+
+
 def _scale_all(grads, g):
     """grads *= g (the scalar upstream gradient of a fused loss) for every tensor of the list, in one multi-tensor
-    launch; the buffers are owned by the Function that produced them."""
+    launch; the buffers are owned by the Function that produced them.  Skipped when the loss is the root handed to
+    backward_root() (g is the constant 1)."""
+    one = _ones.get(g.device)
+    if _cfg.get("root_loss") is not None and one is not None and g.data_ptr() == one.data_ptr():
+        return
     ts = [t for t in grads if t is not None]
     if ts:
         torch._foreach_mul_(ts, g.reshape(()).to(ts[0].dtype))
@@ -914,9 +1159,7 @@ class FusedFirstLayer:
             raise RuntimeError("fused first layer: two backward() passes without optimizer.step()")
         st = opt.state[p]
         if len(st) == 0:
-            st["step"] = 0
-            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            _new_adam_state(opt, p)
         t = st["step"] + 1
         b1, b2 = self.group["betas"]
         sh = shadow_of(p)
@@ -1090,9 +1333,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW needs contiguous parameters")
                 st = self.state[p]
                 if len(st) == 0:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    _new_adam_state(self, p)
                 dyn = self.step_state
                 if dyn is None:
                     st["step"] += 1

@@ -78,29 +78,57 @@ class HipFCNN(nn.Sequential):
         return x
 
 
-def encoder_branch(fcnn, final, x, cov=None):
-    """final(fcnn(x, cov)) for an encoder branch (model.py:124-143: hidden_rep [+ extra_linear_rep], hidden_lib + its
-    head).  The reference's default shape -- sparse minibatch, no covariate block, two FCNN layers with LayerNorm and
-    no BatchNorm -- runs as the first-layer product plus ONE fused tail kernel (ops.enc_branch); everything else goes
-    layer by layer."""
+def _branch_spec(fcnn, final, x, cov):
+    """The tensors of an encoder branch the fused path (ops.enc_branches) takes, or None when the branch has another
+    shape than the reference's default (sparse minibatch, no covariate block, two FCNN layers with LayerNorm and no
+    BatchNorm, a Linear with bias behind them or none)."""
     groups = fcnn._groups() if isinstance(fcnn, HipFCNN) else None
-    if groups is not None and len(groups) == 2:
-        (l1, n1, a1, bn1, d1), (l2, n2, a2, bn2, d2) = groups
-        W3 = None if final is None else final.weight
-        try:
-            slope = _slope_of(a1)
-            same_act = _slope_of(a2) == slope
-        except NotImplementedError:
-            same_act = False
-        if same_act and bn1 is None and bn2 is None and (final is None or final.bias is not None) and l2.bias is not None \
-                and ops.enc_branch_supported(x, cov, l1.weight, l2.weight, W3, n1 is not None, n2 is not None) \
-                and n1.elementwise_affine and n2.elementwise_affine:
-            p1 = float(d1.p) if (fcnn.training and d1.p > 0) else 0.0
-            p2 = float(d2.p) if (fcnn.training and d2.p > 0) else 0.0
-            return ops.enc_branch(x, l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias, n2.weight, n2.bias,
-                                  W3, None if final is None else final.bias, slope, p1, p2, n1.eps, n2.eps)
-    h = fcnn(x, cov)
-    return h if final is None else final(h)
+    if groups is None or len(groups) != 2:
+        return None
+    (l1, n1, a1, bn1, d1), (l2, n2, a2, bn2, d2) = groups
+    W3 = None if final is None else final.weight
+    try:
+        slope = _slope_of(a1)
+        same_act = _slope_of(a2) == slope
+    except NotImplementedError:
+        return None
+    if not (same_act and bn1 is None and bn2 is None and (final is None or final.bias is not None) and l2.bias is not None
+            and ops.enc_branch_supported(x, cov, l1.weight, l2.weight, W3, n1 is not None, n2 is not None)
+            and n1.elementwise_affine and n2.elementwise_affine):
+        return None
+    return dict(W1=l1.weight, b1=l1.bias, g1=n1.weight, be1=n1.bias, W2=l2.weight, b2=l2.bias, g2=n2.weight, be2=n2.bias,
+                W3=W3, b3=None if final is None else final.bias, eps1=n1.eps, eps2=n2.eps, slope=slope,
+                p1=float(d1.p) if (fcnn.training and d1.p > 0) else 0.0,
+                p2=float(d2.p) if (fcnn.training and d2.p > 0) else 0.0)
+
+
+def encoder_branches(branches, x, cov=None):
+    """[final(fcnn(x, cov)) for (fcnn, final) in branches] for the branches of one encoder (model.py:124-143: hidden_rep
+    [+ extra_linear_rep], hidden_lib + its head).  Branches of the reference's default shape run together: their
+    first-layer products as one launch over the packed weights (precision 'bf16') and their tails as ONE fused kernel
+    (ops.enc_branches); everything else goes layer by layer."""
+    specs = [_branch_spec(f, fin, x, cov) for f, fin in branches]
+    outs = [None] * len(branches)
+    fusable = [i for i, sp in enumerate(specs) if sp is not None]
+    by_slope = {}
+    for i in fusable:
+        by_slope.setdefault(specs[i]["slope"], []).append(i)
+    for slope, idx in by_slope.items():
+        idx = idx[:ops.ENC_MAX_BRANCHES]
+        if len(idx) == 2 and ops.get_precision() == "bf16":
+            ops.pack_first_layers(specs[idx[0]]["W1"], specs[idx[1]]["W1"])
+        res = ops.enc_branches(x, [specs[i] for i in idx], slope)
+        for i, r in zip(idx, res):
+            outs[i] = r
+    for i, (f, fin) in enumerate(branches):
+        if outs[i] is None:
+            h = f(x, cov)
+            outs[i] = h if fin is None else fin(h)
+    return outs
+
+
+def encoder_branch(fcnn, final, x, cov=None):
+    return encoder_branches([(fcnn, final)], x, cov)[0]
 
 
 def FCNN(layers, layernorm=True, activation=nn.ReLU(), batchnorm=False, dropout_rate=0):
@@ -208,7 +236,7 @@ def train_net(input, output, library_size, encoder, decoder, optimizer, likeliho
     training_loss = _predictor_loss(input, output, library_size, encoder, decoder, likelihood_type, add_cov,
                                     input_batch, output_batch)
     optimizer.zero_grad()
-    training_loss.backward()
+    ops.backward_root(training_loss)
     optimizer.step()
     return training_loss.detach()
 

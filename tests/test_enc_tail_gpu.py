@@ -137,8 +137,8 @@ def test_encoder_branch_with_dropout(N3):
 
     def run(s1, s2, grad):
         d = {k: v.clone().to(DEV).requires_grad_(grad) for k, v in P.items()}
-        out = ops.EncBranchFn.apply(tiles, d["W1"], d["b1"], d["g1"], d["be1"], d["W2"], d["b2"], d["g2"], d["be2"],
-                                    d.get("W3"), d.get("b3"), 0.01, p1, p2, s1, s2, 1e-5, 1e-5, None, None, None)
+        out = ops.enc_branch(tiles, d["W1"], d["b1"], d["g1"], d["be1"], d["W2"], d["b2"], d["g2"], d["be2"],
+                             d.get("W3"), d.get("b3"), 0.01, p1, p2, seeds=(s1, s2))
         return d, out
     d, out = run(seed1, seed2, True)
     (out * wout.to(DEV)).sum().backward()
@@ -147,3 +147,80 @@ def test_encoder_branch_with_dropout(N3):
         _check(k, d[k].grad, q[k].grad, 2e-4)
     assert torch.equal(run(seed1, seed2, False)[1], out.detach())
     assert not torch.equal(run(99, 98, False)[1], out.detach())
+
+
+@pytest.mark.parametrize("prec,pack", [("fp32", False), ("bf16", False), ("bf16", True)])
+@pytest.mark.parametrize("B", [1024, 203])
+def test_two_branches_in_one_launch(prec, pack, B):
+    """hidden_rep (+ extra_linear_rep, N3 = H2) and hidden_lib (+ head, N3 = 1) of one encoder through ops.enc_branches:
+    one tail launch each way for both; with packed first-layer weights (precision 'bf16') also one first-layer product
+    and one weight-gradient launch.  Every output and gradient against the fp64 restatement of each branch."""
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision(prec)
+    try:
+        F, H1, H2 = 1000, 900, 40
+        rng = np.random.default_rng(B)
+        m = _csr(rng, B + 5, F, 0.06)
+        rows = rng.permutation(B + 5)[:B]
+        x = torch.tensor(np.asarray(m[rows].todense(), dtype=np.float32))
+        rnd = (lambda t: t.bfloat16().double()) if prec == "bf16" else (lambda t: t.double())
+        refs, devs, wouts = [], [], []
+        for bi, N3 in enumerate((H2, 1)):
+            g, P, q, out_r = _draw(F, H1, H2, N3, x, rnd, 50 + bi)
+            wout = torch.randn(B, N3, generator=g)
+            (out_r * wout.double()).sum().backward()
+            refs.append((P, q, out_r))
+            wouts.append(wout)
+            devs.append({k: v.clone().to(DEV).requires_grad_(True) for k, v in P.items()})
+        if pack:
+            assert ops.pack_first_layers(devs[0]["W1"], devs[1]["W1"])
+            assert devs[1]["W1"].data_ptr() == devs[0]["W1"].data_ptr() + 4 * H1 * F
+            assert torch.equal(devs[1]["W1"].detach().cpu(), refs[1][0]["W1"])
+        tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), rows)
+        outs = ops.enc_branches(tiles, devs, 0.01)
+        sum((o * w.to(DEV)).sum() for o, w in zip(outs, wouts)).backward()
+        rt = 2e-4 if prec == "fp32" else 2e-3
+        for bi in range(2):
+            P, q, out_r = refs[bi]
+            _check(f"out{bi}", outs[bi], out_r, rt)
+            for k in P:
+                assert devs[bi][k].grad is not None, (bi, k)
+                _check(f"{k}{bi}", devs[bi][k].grad, q[k].grad, rt * (10 if (k == "W1" and prec == "bf16") else 1))
+    finally:
+        S.set_precision("fp32")
+
+
+def test_packed_pair_fused_adamw_matches_separate_weights():
+    """Two steps of the fused weight-gradient + AdamW launch over a packed pair against the same two steps with
+    unpacked weights (two launches): identical parameters (same kernel arithmetic, other tiling of the rows)."""
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision("bf16")
+    try:
+        B, F, H1, H2 = 256, 600, 132, 16
+        rng = np.random.default_rng(9)
+        m = _csr(rng, B, F, 0.1)
+        tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), np.arange(B))
+        x = torch.tensor(np.asarray(m.todense(), dtype=np.float32))
+        res = []
+        for pack in (False, True):
+            devs = []
+            for bi, N3 in enumerate((H2, 1)):
+                g, P, q, out_r = _draw(F, H1, H2, N3, x, lambda t: t.double(), 70 + bi)
+                devs.append({k: torch.nn.Parameter(v.clone().to(DEV)) for k, v in P.items()})
+            if pack:
+                assert ops.pack_first_layers(devs[0]["W1"], devs[1]["W1"])
+            opt = S.FusedAdamW([{"params": [p for d in devs for p in d.values()], "weight_decay": 1e-2, "lr": 1e-2}])
+            opt.fuse_first_layer(devs[0]["W1"], devs[1]["W1"])
+            for _ in range(2):
+                opt.zero_grad()
+                outs = ops.enc_branches(tiles, devs, 0.01)
+                sum((o * o).sum() for o in outs).backward()
+                opt.step()
+            res.append([{k: v.detach().clone() for k, v in d.items()} for d in devs])
+        for a, b in zip(*res):
+            for k in a:
+                assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), k
+    finally:
+        S.set_precision("fp32")
