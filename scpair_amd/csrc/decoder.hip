@@ -1,5 +1,6 @@
 // Host API of the fused decoder kernels (kernels: decoder_kernel.h, instantiated per precision in
 // decoder_{ber,nb}_ns{1,3}.hip).
+#include <cstdlib>
 #include "decoder_kernel.h"
 
 int dec_run_ber_ns1(int mode, const DecArgs& g, int kp, int grid, hipStream_t stream);
@@ -110,7 +111,13 @@ extern "C" int scp_dec_kp(int K) { return K <= 16 ? 16 : (K <= 48 ? 48 : 64); }
 // cell blocks per workgroup: enough (chunk x cell-group) workgroups to fill the chip a few times over
 static int dec_cpg(int B, int F) {
   int nchunk = scp_dec_chunks(F), ncb = (B + CB - 1) / CB;
-  int ncg = (1024 + nchunk - 1) / nchunk;
+  static int target = 0;
+  if (!target) {
+    const char* e = getenv("SCPAIR_DEC_WGS");
+    target = e ? atoi(e) : 2048;
+    if (target < 1) target = 2048;
+  }
+  int ncg = (target + nchunk - 1) / nchunk;
   if (ncg > ncb) ncg = ncb;
   if (ncg < 1) ncg = 1;
   return (ncb + ncg - 1) / ncg;

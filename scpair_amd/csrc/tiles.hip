@@ -13,14 +13,14 @@
 #include "common.h"
 #include "scpair_hip.h"
 
-// Build, without global atomics:
-//   1. tiles_bounds_kernel  one thread per (batch row, feature slice): binary search of the slice's first entry in
-//                           the (column-sorted) CSR row; integer atomics add the row's slice length to the
-//                           (cell block, slice) total
-//   2. tiles_scan_kernel    one workgroup: exclusive scan of the (cell block, slice) totals -> slice bases
+// Build, without floating-point atomics (integer atomics only: the result does not depend on their order):
+//   1. tiles_rowscan_kernel one workgroup per batch row: one streaming pass over the row's (column-sorted) indices finds
+//                           where every feature slice starts (neighbouring entries that fall into different slices),
+//                           integer atomics add the slice lengths to the (cell block, slice) totals; the same pass sums
+//                           the row's values (library size, fixed order) and counts its NaNs when asked for
+//   2. tiles_scan_kernel    one workgroup: exclusive scan of the (cell block, slice) totals -> slice bases; NaN total
 //   3. tiles_place_kernel   one workgroup per (slice, cell block): per-feature counts, their scan and the ranks of
 //                           the entries inside a bucket all live in LDS; writes ptr, key and val
-//   4. tiles_rowsum_kernel  lib[b] = row sum (fixed order), NaN count            (only when asked for)
 #define TILE_MAX_SF 2048   // features per slice (LDS histogram), a power of two >= 256
 
 static int tiles_sf(int B, int F) {
@@ -29,44 +29,106 @@ static int tiles_sf(int B, int F) {
   return sf;
 }
 
-__global__ __launch_bounds__(256) void tiles_bounds_kernel(const int64_t* __restrict__ indptr,
-                                                           const int32_t* __restrict__ indices,
-                                                           const int64_t* __restrict__ rows, int B, int sf, int nslice,
-                                                           int32_t* __restrict__ bnd /* [B][nslice+1] */,
-                                                           int32_t* __restrict__ tot /* [ncb][nslice], zeroed */,
-                                                           int32_t* __restrict__ nnan /* cleared here, counted later */) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0 && nnan) nnan[0] = 0;
-  if (i >= B * (nslice + 1)) return;
-  int b = i / (nslice + 1), sidx = i % (nslice + 1);
-  int64_t r = rows[b];
-  int64_t e0 = indptr[r];
-  int len = (int)(indptr[r + 1] - e0);
-  int lo = 0;
-  if (sidx == nslice) {
-    lo = len;
-  } else if (sidx > 0) {
-    int target = sidx * sf, hi = len;
-    const int32_t* ix = indices + e0;
-    while (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      if (ix[mid] < target) lo = mid + 1; else hi = mid;
+__global__ __launch_bounds__(256) void tiles_rowscan_kernel(const int64_t* __restrict__ indptr,
+                                                            const int32_t* __restrict__ indices,
+                                                            const float* __restrict__ values,
+                                                            const int64_t* __restrict__ rows, int lsf /* log2 sf */,
+                                                            int nslice, int32_t* __restrict__ bnd /* [B][nslice+1] */,
+                                                            int32_t* __restrict__ tot /* [ncb][nslice], zeroed */,
+                                                            float* __restrict__ lib, int32_t* __restrict__ nnrow) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t r = rows[b];
+  const int64_t e0 = indptr[r];
+  const int len = (int)(indptr[r + 1] - e0);
+  const int32_t* ix = indices + e0;
+  int32_t* bo = bnd + (long)b * (nslice + 1);
+  // entry e opens the slices (slice of entry e-1, slice of entry e]
+  {
+    int e = tid;
+    for (; e + 768 < len; e += 1024) {             // four entries (and their left neighbours) per trip: eight loads in flight
+      int cu[4], pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        cu[u] = ix[e + 256 * u];
+        pv[u] = ix[max(e + 256 * u - 1, 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int ee = e + 256 * u;
+        const int cur = cu[u] >> lsf, prev = ee ? (pv[u] >> lsf) : -1;
+        for (int sidx = prev + 1; sidx <= cur; sidx++) bo[sidx] = ee;
+      }
+    }
+    for (; e < len; e += 256) {
+      const int cur = ix[e] >> lsf;
+      const int prev = e ? (ix[e - 1] >> lsf) : -1;
+      for (int sidx = prev + 1; sidx <= cur; sidx++) bo[sidx] = e;
     }
   }
-  bnd[i] = lo;
-  // lo is the start of slice sidx and the end of slice sidx-1
-  int cb = b >> 6;
-  if (sidx < nslice && lo) atomicSub(&tot[cb * nslice + sidx], lo);
-  if (sidx > 0 && lo) atomicAdd(&tot[cb * nslice + sidx - 1], lo);
+  const int last = len ? (ix[len - 1] >> lsf) : -1;
+  for (int sidx = last + 1 + tid; sidx <= nslice; sidx += 256) bo[sidx] = len;
+  float s = 0.f;
+  int nn = 0;
+  const bool want_sum = lib || (nnrow && values);
+  if (want_sum && values) {
+    const float* vx = values + e0;
+    int e = tid;
+    for (; e + 768 < len; e += 1024) {
+      float v0 = vx[e], v1 = vx[e + 256], v2 = vx[e + 512], v3 = vx[e + 768];
+      if (v0 != v0) nn++; else s += v0;
+      if (v1 != v1) nn++; else s += v1;
+      if (v2 != v2) nn++; else s += v2;
+      if (v3 != v3) nn++; else s += v3;
+    }
+    for (; e < len; e += 256) {
+      float v = vx[e];
+      if (v != v) nn++; else s += v;
+    }
+  }
+  __syncthreads();                                 // the row's slice starts are complete (and visible to the workgroup)
+  const int cb = b >> 6;
+  for (int sidx = tid; sidx < nslice; sidx += 256) {
+    const int c = bo[sidx + 1] - bo[sidx];
+    if (c) atomicAdd(&tot[cb * nslice + sidx], c);
+  }
+  if (want_sum) {
+    if (values) {
+      s = block_sum(s, red);
+      const float t = block_sum((float)nn, red);
+      if (tid == 0 && nnrow) nnrow[b] = (int)t;
+    } else {
+      s = (float)len;                               // implicit ones cannot hold NaN
+      if (tid == 0 && nnrow) nnrow[b] = 0;
+    }
+    if (lib && tid == 0) lib[b] = s;
+  }
 }
 
 // exclusive scan of tot[n] in place (single workgroup of 1024); also the two closing ptr entries
-__global__ __launch_bounds__(1024) void tiles_scan_kernel(int32_t* __restrict__ tot, int n, int32_t* __restrict__ ptr_end) {
+__global__ __launch_bounds__(1024) void tiles_scan_kernel(int32_t* __restrict__ tot, int n, int32_t* __restrict__ ptr_end,
+                                                          const int32_t* __restrict__ nnrow, int B,
+                                                          int32_t* __restrict__ nnan) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (nnan) {                                      // total NaN count of the batch (per-row counts: tiles_rowscan_kernel)
+    int32_t c = 0;
+    if (nnrow)
+      for (int i = threadIdx.x; i < B; i += 1024) c += nnrow[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) wsum[w] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int32_t t = 0;
+      for (int k = 0; k < 16; k++) t += wsum[k];
+      nnan[0] = t;
+    }
+    __syncthreads();
+  }
   for (int c0 = 0; c0 < n; c0 += 1024) {
     int i = c0 + threadIdx.x;
     int32_t v = (i < n) ? tot[i] : 0;
@@ -120,23 +182,26 @@ __global__ __launch_bounds__(256) void tiles_place_kernel(const int64_t* __restr
     row_e0[tid] = e0; row_lo[tid] = lo; row_hi[tid] = hi;
   }
   __syncthreads();
-  // pass 1: per-feature counts.  Wave w owns rows w, w+4, ...; four rows of loads in flight.
-  for (int g = 0; g < 16; g += 4) {
-    int c[4];
+  // Wave w owns rows w, w+4, ..., w+60.  The first 64 slice entries of each of its 16 rows are loaded ONCE (sixteen
+  // independent loads per lane in flight) and stay in registers for both passes; longer rows (rare: a slice holds
+  // sf / F of a row) loop over the rest.
+  int c[16];
+  float v[16];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int r = w + 4 * (g + k);
-      int e = row_lo[r] + lane;
-      c[k] = (e < row_hi[r]) ? indices[row_e0[r] + e] : -1;
-    }
+  for (int k = 0; k < 16; k++) {
+    const int r = w + 4 * k;
+    const int e = row_lo[r] + lane;
+    const bool ok = e < row_hi[r];
+    c[k] = ok ? indices[row_e0[r] + e] : -1;
+    v[k] = (ok && val && values) ? values[row_e0[r] + e] : 1.f;
+  }
+  // pass 1: per-feature counts
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (c[k] >= 0) atomicAdd(&cnt[c[k] - f0], 1);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int r = w + 4 * (g + k);
-      for (int e = row_lo[r] + 64 + lane; e < row_hi[r]; e += 64) atomicAdd(&cnt[indices[row_e0[r] + e] - f0], 1);
-    }
+  for (int k = 0; k < 16; k++)
+    if (c[k] >= 0) atomicAdd(&cnt[c[k] - f0], 1);
+  for (int k = 0; k < 16; k++) {
+    const int r = w + 4 * k;
+    for (int e = row_lo[r] + 64 + lane; e < row_hi[r]; e += 64) atomicAdd(&cnt[indices[row_e0[r] + e] - f0], 1);
   }
   __syncthreads();
   // exclusive scan of cnt[0..sf): thread t owns E consecutive features
@@ -171,73 +236,23 @@ __global__ __launch_bounds__(256) void tiles_place_kernel(const int64_t* __restr
   }
   __syncthreads();
   // pass 2: place
-  int rl_base = 0;
-  for (int g = 0; g < 16; g += 4) {
-    int c[4];
-    float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int r = w + 4 * (g + k);
-      int e = row_lo[r] + lane;
-      bool ok = e < row_hi[r];
-      c[k] = ok ? indices[row_e0[r] + e] : -1;
-      v[k] = (ok && val && values) ? values[row_e0[r] + e] : 1.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int r = w + 4 * (g + k);
-      if (c[k] >= 0) {
-        int pos = base + atomicAdd(&cnt[c[k] - f0], 1);
-        key[pos] = (c[k] << 6) | r;
-        if (val) val[pos] = v[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int r = w + 4 * (g + k);
-      for (int e = row_lo[r] + 64 + lane; e < row_hi[r]; e += 64) {
-        int col = indices[row_e0[r] + e];
-        int pos = base + atomicAdd(&cnt[col - f0], 1);
-        key[pos] = (col << 6) | r;
-        if (val) val[pos] = values ? values[row_e0[r] + e] : 1.f;
-      }
+  for (int k = 0; k < 16; k++) {
+    const int r = w + 4 * k;
+    if (c[k] >= 0) {
+      const int pos = base + atomicAdd(&cnt[c[k] - f0], 1);
+      key[pos] = (c[k] << 6) | r;
+      if (val) val[pos] = v[k];
     }
   }
-  (void)rl_base;
-}
-
-// lib[b] = sum of the row's values (NaNs skipped and counted); one workgroup per row, fixed order
-__global__ __launch_bounds__(256) void tiles_rowsum_kernel(const int64_t* __restrict__ indptr,
-                                                           const float* __restrict__ values,
-                                                           const int64_t* __restrict__ rows, int B,
-                                                           float* __restrict__ lib, int32_t* __restrict__ nnan) {
-  __shared__ float red[16];
-  int b = blockIdx.x, tid = threadIdx.x;
-  int64_t r = rows[b];
-  int64_t e0 = indptr[r], e1 = indptr[r + 1];
-  float s = 0.f;
-  int nn = 0;
-  if (values) {
-    int64_t e = e0 + tid;
-    for (; e + 768 < e1; e += 1024) {
-      float v0 = values[e], v1 = values[e + 256], v2 = values[e + 512], v3 = values[e + 768];
-      if (v0 != v0) nn++; else s += v0;
-      if (v1 != v1) nn++; else s += v1;
-      if (v2 != v2) nn++; else s += v2;
-      if (v3 != v3) nn++; else s += v3;
+  for (int k = 0; k < 16; k++) {
+    const int r = w + 4 * k;
+    for (int e = row_lo[r] + 64 + lane; e < row_hi[r]; e += 64) {
+      const int col = indices[row_e0[r] + e];
+      const int pos = base + atomicAdd(&cnt[col - f0], 1);
+      key[pos] = (col << 6) | r;
+      if (val) val[pos] = values ? values[row_e0[r] + e] : 1.f;
     }
-    for (; e < e1; e += 256) {
-      float v = values[e];
-      if (v != v) nn++; else s += v;
-    }
-    s = block_sum(s, red);
-  } else {
-    s = (float)(e1 - e0);
-  }
-  if (lib && tid == 0) lib[b] = s;
-  if (nnan && values) {
-    float t = block_sum((float)nn, red);
-    if (tid == 0 && t > 0.f) atomicAdd(nnan, (int)t);
   }
 }
 
@@ -245,7 +260,7 @@ extern "C" long scp_tiles_ptr_len(int B, int F) { return (long)((B + 63) / 64) *
 extern "C" long scp_tiles_ws_len(int B, int F) {
   int sf = tiles_sf(B, F);
   long nslice = (F + sf - 1) / sf, ncb = (B + 63) / 64;
-  return (long)B * (nslice + 1) + ncb * nslice + 2;
+  return (long)B * (nslice + 1) + ncb * nslice + B + 2;
 }
 
 extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* rows,
@@ -257,22 +272,22 @@ extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, co
   SCP_CHECK(F < (1 << 25), SCP_ERR_SHAPE, "scp_tiles_build: F=%d exceeds the 2^25 key range", F);
   int sf = tiles_sf(B, F);
   int nslice = (F + sf - 1) / sf, ncb = (B + 63) / 64;
+  int lsf = 0;
+  while ((1 << lsf) < sf) lsf++;
   int32_t* bnd = ws;
   int32_t* tot = ws + (long)B * (nslice + 1);
+  int32_t* nnrow = tot + (long)ncb * nslice;
+  const bool want_sum = lib || (nnan && values);
   SCP_HIP(hipMemsetAsync(tot, 0, (size_t)ncb * nslice * sizeof(int32_t), stream));
-  int nthr = B * (nslice + 1);
-  hipLaunchKernelGGL(tiles_bounds_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, indptr, indices, rows, B, sf,
-                     nslice, bnd, tot, nnan);
+  hipLaunchKernelGGL(tiles_rowscan_kernel, dim3(B), dim3(256), 0, stream, indptr, indices, values, rows, lsf, nslice, bnd,
+                     tot, lib, want_sum ? nnrow : (int32_t*)nullptr);
   SCP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tiles_scan_kernel, dim3(1), dim3(1024), 0, stream, tot, ncb * nslice, ptr + (long)ncb * F);
+  hipLaunchKernelGGL(tiles_scan_kernel, dim3(1), dim3(1024), 0, stream, tot, ncb * nslice, ptr + (long)ncb * F,
+                     want_sum ? nnrow : (const int32_t*)nullptr, B, nnan);
   SCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(tiles_place_kernel, dim3(nslice, ncb), dim3(256), 0, stream, indptr, indices, values, rows, B, F,
                      sf, nslice, bnd, tot, ptr, key, val);
   SCP_LAUNCH_CHECK();
-  if (lib || (nnan && values)) {             // implicit ones cannot hold NaN: nothing to count
-    hipLaunchKernelGGL(tiles_rowsum_kernel, dim3(B), dim3(256), 0, stream, indptr, values, rows, B, lib, nnan);
-    SCP_LAUNCH_CHECK();
-  }
   return SCP_OK;
 }
 
