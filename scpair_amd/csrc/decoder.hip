@@ -19,30 +19,9 @@ static int dec_dispatch(const DecArgs& g, int ns, int grid, hipStream_t stream) 
   return ns == 1 ? dec_run_nb_ns1(MODE, g, kp, grid, stream) : dec_run_nb_ns3(MODE, g, kp, grid, stream);
 }
 
-// ---- finishing kernels ------------------------------------------------------------------------------
+// ---- finishing reductions --------------------------------------------------------------------------
 // Workgroup = 64 outputs x 16 chunk groups (dim3(64,16)): group y folds chunks y, y+16, ...; the 16 group
 // results are then combined in ascending order, so every output is a fixed-order (deterministic) reduction.
-// dh[b][k] = sum_chunk slab[chunk][b][k]
-__global__ __launch_bounds__(1024) void dec_finish_dh_kernel(const float* __restrict__ slab, int nchunk, int B, int K,
-                                                             int KP, float* __restrict__ dh, long lddh) {
-  __shared__ float red[16][64];
-  int x = threadIdx.x, y = threadIdx.y;
-  long j = (long)blockIdx.x * 64 + x;   // b * KP + k
-  bool ok = j < (long)B * KP;
-  float s = ok ? strided_sum16(slab + j, (long)B * KP, nchunk, y) : 0.f;
-  red[y][x] = s;
-  __syncthreads();
-  if (y == 0 && ok) {
-    int b = (int)(j / KP), k = (int)(j % KP);
-    if (k < K) {
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; q++) t += red[q][x];
-      dh[(long)b * lddh + k] = t;
-    }
-  }
-}
-
 // row_mode 0: out0[b] = sum_chunk slab[.][b][0]                    (Ber dl / NB T)
 // row_mode 1: (m,s) merge -> out0[b] = m + log s                    (NB log-sum-exp)
 // row_mode 2: like 0, and out1[b] = out0[b] * dscale(lat[b])        (NB dlatent_lib = T * lrelu'(lat))
@@ -52,57 +31,130 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
   s = s * e1 + s2 * e2;
   m = mn;
 }
-__global__ __launch_bounds__(1024) void dec_finish_rows_kernel(const float* __restrict__ slab, int nchunk, int B,
-                                                               int row_mode, float scale_, const float* __restrict__ aux,
-                                                               float* __restrict__ out0, float* __restrict__ out1) {
+
+// ---- all finishing reductions of a decoder pass in ONE launch ------------------------------------------------------
+// The workgroups (dim3(64, 16)) of the launch are split into ranges, one per job: the dh slabs, a per-cell row
+// reduction, up to four cell-group slab sums (dW, db, dfs, dtheta) and the loss.  Each job keeps the fixed summation
+// order of the stand-alone kernels above.
+struct FinishJobs {
+  // dh[b][k] = sum over chunks (blocks [0, n_dh))
+  const float* dh_slab; float* dh; long lddh; int K, KP, n_dh;
+  // rows (blocks [n_dh, n_dh + n_rows)): row_mode as dec_finish_rows_kernel
+  const float* row_slab; int row_mode; float row_scale; const float* row_aux; float* row_out0; float* row_out1; int n_rows;
+  // cell-group slab sums: out[r][c] = sum_y slab[y * stride + r * cols + c]  (blocks of 64 x 16 elements each)
+  const float* sl_src[4]; float* sl_dst[4]; long sl_stride[4]; long sl_n[4]; int sl_cols[4]; long sl_ldo[4]; int sl_blk0[4];
+  int nslab_jobs, ncg;
+  // loss (one block, the last): loss = sum(part[0..nblk)) / (n_total - nnan)
+  const double* loss_part; int nblk; double n_total; const int32_t* nnan; float* loss; int loss_blk;
+  int nchunk, B;
+};
+
+__global__ __launch_bounds__(1024) void dec_finish_all_kernel(FinishJobs J) {
   __shared__ float red[2][16][64];
-  int x = threadIdx.x, y = threadIdx.y;
-  int b = blockIdx.x * 64 + x;
-  bool ok = b < B;
-  if (row_mode == 1) {
-    float m = -INFINITY, s = 0.f;
-    if (ok) {
-      int c = y;
-      for (; c + 16 < nchunk; c += 32) {
-        float2 p0 = *(const float2*)&slab[((long)c * B + b) * 2];
-        float2 p1 = *(const float2*)&slab[((long)(c + 16) * B + b) * 2];
-        lse_merge(m, s, p0.x, p0.y);
-        lse_merge(m, s, p1.x, p1.y);
-      }
-      for (; c < nchunk; c += 16) {
-        float2 p0 = *(const float2*)&slab[((long)c * B + b) * 2];
-        lse_merge(m, s, p0.x, p0.y);
-      }
-    }
-    red[0][y][x] = m;
-    red[1][y][x] = s;
-    __syncthreads();
-    if (y == 0 && ok) {
-      float mm = -INFINITY, ss = 0.f;
-      for (int q = 0; q < 16; q++) lse_merge(mm, ss, red[0][q][x], red[1][q][x]);
-      out0[b] = mm + logf(ss);
-    }
-  } else {
-    float s = ok ? strided_sum16(slab + (long)b * 2, (long)B * 2, nchunk, y) : 0.f;
+  __shared__ double dred[16];
+  const int x = threadIdx.x, y = threadIdx.y;
+  const int blk = blockIdx.x;
+  if (blk < J.n_dh) {
+    const long j = (long)blk * 64 + x;   // b * KP + k
+    const bool ok = j < (long)J.B * J.KP;
+    const float s = ok ? strided_sum16(J.dh_slab + j, (long)J.B * J.KP, J.nchunk, y) : 0.f;
     red[0][y][x] = s;
     __syncthreads();
     if (y == 0 && ok) {
-      float t = 0.f;
+      const int b = (int)(j / J.KP), k = (int)(j % J.KP);
+      if (k < J.K) {
+        float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < 16; q++) t += red[0][q][x];
-      out0[b] = t;
-      if (row_mode == 2 && out1) out1[b] = t * scale_ * ((aux[b] > 0.f) ? 1.f : 0.01f);
+        for (int q = 0; q < 16; q++) t += red[0][q][x];
+        J.dh[(long)b * J.lddh + k] = t;
+      }
+    }
+    return;
+  }
+  if (blk < J.n_dh + J.n_rows) {
+    const int b = (blk - J.n_dh) * 64 + x;
+    const bool ok = b < J.B;
+    const float* slab = J.row_slab;
+    if (J.row_mode == 1) {
+      float m = -INFINITY, s = 0.f;
+      if (ok) {
+        int c = y;
+        for (; c + 16 < J.nchunk; c += 32) {
+          const float2 p0 = *(const float2*)&slab[((long)c * J.B + b) * 2];
+          const float2 p1 = *(const float2*)&slab[((long)(c + 16) * J.B + b) * 2];
+          lse_merge(m, s, p0.x, p0.y);
+          lse_merge(m, s, p1.x, p1.y);
+        }
+        for (; c < J.nchunk; c += 16) {
+          const float2 p0 = *(const float2*)&slab[((long)c * J.B + b) * 2];
+          lse_merge(m, s, p0.x, p0.y);
+        }
+      }
+      red[0][y][x] = m;
+      red[1][y][x] = s;
+      __syncthreads();
+      if (y == 0 && ok) {
+        float mm = -INFINITY, ss = 0.f;
+        for (int q = 0; q < 16; q++) lse_merge(mm, ss, red[0][q][x], red[1][q][x]);
+        J.row_out0[b] = mm + logf(ss);
+      }
+    } else {
+      const float s = ok ? strided_sum16(slab + (long)b * 2, (long)J.B * 2, J.nchunk, y) : 0.f;
+      red[0][y][x] = s;
+      __syncthreads();
+      if (y == 0 && ok) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) t += red[0][q][x];
+        J.row_out0[b] = t;
+        if (J.row_mode == 2 && J.row_out1) J.row_out1[b] = t * J.row_scale * ((J.row_aux[b] > 0.f) ? 1.f : 0.01f);
+      }
+    }
+    return;
+  }
+  if (blk == J.loss_blk) {
+    // fixed order: thread t adds partials t, t + 1024, ...; waves, then the 16 wave sums, in ascending order
+    const int t = y * 64 + x;
+    double s = 0.0;
+    for (int i = t; i < J.nblk; i += 1024) s += J.loss_part[i];
+    s = wave_sum_d(s);
+    if (x == 0) dred[y] = s;
+    __syncthreads();
+    if (t == 0) {
+      double tot = 0.0;
+      for (int q = 0; q < 16; q++) tot += dred[q];
+      const double n = J.n_total - (J.nnan ? (double)J.nnan[0] : 0.0);
+      J.loss[0] = (float)(tot / n);
+    }
+    return;
+  }
+  for (int q = J.nslab_jobs - 1; q >= 0; q--) {
+    if (blk >= J.sl_blk0[q]) {
+      const long i = ((long)(blk - J.sl_blk0[q]) * 16 + y) * 64 + x;
+      if (i < J.sl_n[q]) {
+        float sacc = 0.f;
+        for (int g_ = 0; g_ < J.ncg; g_++) sacc += J.sl_src[q][(long)g_ * J.sl_stride[q] + i];
+        const long r = i / J.sl_cols[q], c = i - r * J.sl_cols[q];
+        J.sl_dst[q][r * J.sl_ldo[q] + c] = sacc;
+      }
+      return;
     }
   }
 }
 
-__global__ void dec_finish_loss_kernel(const double* __restrict__ sum, double n_total, const int32_t* __restrict__ nnan,
-                                       float* __restrict__ loss) {
-  double n = n_total - (nnan ? (double)nnan[0] : 0.0);
-  loss[0] = (float)(sum[0] / n);
+// Lays the jobs out over the block index space and launches; slab jobs only when ncg > 1.
+static int launch_finish(FinishJobs& J, hipStream_t stream) {
+  int nblocks = J.n_dh + J.n_rows;
+  for (int q = 0; q < J.nslab_jobs; q++) {
+    J.sl_blk0[q] = nblocks;
+    nblocks += (int)((J.sl_n[q] + 1023) / 1024);
+  }
+  J.loss_blk = J.loss ? nblocks++ : -1;
+  if (nblocks == 0) return SCP_OK;
+  hipLaunchKernelGGL(dec_finish_all_kernel, dim3(nblocks), dim3(64, 16), 0, stream, J);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
 }
-
-int scp_reduce_partials(const double* part, int n, int ncomp, double* out, hipStream_t stream);
 
 
 extern "C" int scp_dec_chunks(int F) { return (F + DEC_NPT * FT - 1) / (DEC_NPT * FT); }
@@ -168,23 +220,20 @@ static DecPlan make_plan(DecArgs& g, float* ws_f, float* dW, long lddw, float* d
   return p;
 }
 
-// sum the per-cell-group slabs of the per-feature gradients (fixed order -> deterministic)
-static int finish_feature_grads(const DecPlan& p, const DecArgs& g, float* dW, long lddw, float* db, float* dfs,
-                                float* dtheta, hipStream_t stream) {
-  if (p.ncg == 1) return SCP_OK;
-  int rc = scp_slab_reduce(p.dW_slab, (long)g.F * g.K, p.ncg, g.F, g.K, g.K, nullptr, dW, lddw, stream);
-  if (rc) return rc;
-  rc = scp_slab_reduce(p.db_slab, g.F, p.ncg, 1, g.F, g.F, nullptr, db, g.F, stream);
-  if (rc) return rc;
-  if (dfs) {
-    rc = scp_slab_reduce(p.dfs_slab, g.F, p.ncg, 1, g.F, g.F, nullptr, dfs, g.F, stream);
-    if (rc) return rc;
-  }
-  if (dtheta) {
-    rc = scp_slab_reduce(p.dth_slab, g.F, p.ncg, 1, g.F, g.F, nullptr, dtheta, g.F, stream);
-    if (rc) return rc;
-  }
-  return SCP_OK;
+// the cell-group slab sums of the per-feature gradients as jobs of the finishing launch (none when ncg == 1)
+static void add_feature_jobs(FinishJobs& J, const DecPlan& p, const DecArgs& g, float* dW, long lddw, float* db, float* dfs,
+                             float* dtheta) {
+  J.ncg = p.ncg;
+  J.nslab_jobs = 0;
+  if (p.ncg == 1) return;
+  auto add = [&](const float* src, long stride, long n, int cols, float* dst, long ldo) {
+    const int q = J.nslab_jobs++;
+    J.sl_src[q] = src; J.sl_stride[q] = stride; J.sl_n[q] = n; J.sl_cols[q] = cols; J.sl_dst[q] = dst; J.sl_ldo[q] = ldo;
+  };
+  add(p.dW_slab, (long)g.F * g.K, (long)g.F * g.K, g.K, dW, lddw);
+  add(p.db_slab, g.F, g.F, g.F, db, g.F);
+  if (dfs) add(p.dfs_slab, g.F, g.F, g.F, dfs, g.F);
+  if (dtheta) add(p.dth_slab, g.F, g.F, g.F, dtheta, g.F);
 }
 
 extern "C" int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, long ldh, const float* W, long ldw,
@@ -206,23 +255,17 @@ extern "C" int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, l
   int nblk = p.nchunk * p.ncg;
   rc = train ? dec_dispatch<MODE_BER_TRAIN>(g, ns, p.nchunk, stream) : dec_dispatch<MODE_BER_EVAL>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  rc = scp_reduce_partials(ws_d, nblk, 1, ws_d + nblk, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_loss_kernel, dim3(1), dim3(1), 0, stream, ws_d + nblk, (double)B * (double)F, nnan, loss);
-  SCP_LAUNCH_CHECK();
+  FinishJobs J = {};
+  J.nchunk = p.nchunk; J.B = B;
+  J.loss_part = ws_d; J.nblk = nblk; J.n_total = (double)B * (double)F; J.nnan = nnan; J.loss = loss;
   if (train) {
-    rc = finish_feature_grads(p, g, dW, lddw, db, fs ? dfs : nullptr, nullptr, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * p.KP + 63) / 64)), dim3(64, 16), 0, stream, p.dh_slab,
-                       p.nchunk, B, K, p.KP, dh, lddh);
-    SCP_LAUNCH_CHECK();
+    add_feature_jobs(J, p, g, dW, lddw, db, fs ? dfs : nullptr, nullptr);
+    J.dh_slab = p.dh_slab; J.dh = dh; J.lddh = lddh; J.K = K; J.KP = p.KP; J.n_dh = (int)(((long)B * p.KP + 63) / 64);
     if (dlrow && lrow && lrow_n == B) {
-      hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 63) / 64), dim3(64, 16), 0, stream, p.row_slab, p.nchunk, B, 0,
-                         1.f, (const float*)nullptr, dlrow, (float*)nullptr);
-      SCP_LAUNCH_CHECK();
+      J.row_slab = p.row_slab; J.row_mode = 0; J.row_scale = 1.f; J.row_out0 = dlrow; J.n_rows = (B + 63) / 64;
     }
   }
-  return SCP_OK;
+  return launch_finish(J, stream);
 }
 
 // NB decoder (likelihood 'nb'): loss = -mean log NB(y; L*softmax(a'), theta)
@@ -250,31 +293,40 @@ extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, lon
   // pass 1: row log-sum-exp
   rc = dec_dispatch<MODE_NB_STATS>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 63) / 64), dim3(64, 16), 0, stream, p.row_slab, p.nchunk, B, 1, 1.f,
-                     (const float*)nullptr, lse, (float*)nullptr);
-  SCP_LAUNCH_CHECK();
+  {
+    FinishJobs J = {};
+    J.nchunk = p.nchunk; J.B = B;
+    J.row_slab = p.row_slab; J.row_mode = 1; J.row_scale = 1.f; J.row_out0 = lse; J.n_rows = (B + 63) / 64;
+    rc = launch_finish(J, stream);
+    if (rc) return rc;
+  }
   // pass 2: loss and T
   g.rowlse = lse;
   rc = dec_dispatch<MODE_NB_LOSS>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  rc = scp_reduce_partials(ws_d, nblk, 1, ws_d + nblk, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_loss_kernel, dim3(1), dim3(1), 0, stream, ws_d + nblk, (double)B * (double)F,
-                     (const int32_t*)nullptr, loss);
-  SCP_LAUNCH_CHECK();
+  {
+    FinishJobs J = {};
+    J.nchunk = p.nchunk; J.B = B;
+    J.loss_part = ws_d; J.nblk = nblk; J.n_total = (double)B * (double)F; J.loss = loss;
+    if (train) {
+      J.row_slab = p.row_slab; J.row_mode = (dlat && lat) ? 2 : 0; J.row_scale = -1.f / ((float)B * (float)F);
+      J.row_aux = lat; J.row_out0 = T; J.row_out1 = dlat; J.n_rows = (B + 63) / 64;
+    }
+    rc = launch_finish(J, stream);
+    if (rc) return rc;
+  }
   if (!train) return SCP_OK;
-  float sc = -1.f / ((float)B * (float)F);
-  hipLaunchKernelGGL(dec_finish_rows_kernel, dim3((B + 63) / 64), dim3(64, 16), 0, stream, p.row_slab, p.nchunk, B,
-                     (dlat && lat) ? 2 : 0, sc, lat, T, dlat);
-  SCP_LAUNCH_CHECK();
   // pass 3: gradients
   g.rowT = T;
   rc = dec_dispatch<MODE_NB_GRAD>(g, ns, p.nchunk, stream);
   if (rc) return rc;
-  rc = finish_feature_grads(p, g, dW, lddw, db, fs ? dfs : nullptr, theta_param ? dtheta : nullptr, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(dec_finish_dh_kernel, dim3((unsigned)(((long)B * p.KP + 63) / 64)), dim3(64, 16), 0, stream, p.dh_slab,
-                     p.nchunk, B, K, p.KP, dh, lddh);
-  SCP_LAUNCH_CHECK();
+  {
+    FinishJobs J = {};
+    J.nchunk = p.nchunk; J.B = B;
+    add_feature_jobs(J, p, g, dW, lddw, db, fs ? dfs : nullptr, theta_param ? dtheta : nullptr);
+    J.dh_slab = p.dh_slab; J.dh = dh; J.lddh = lddh; J.K = K; J.KP = p.KP; J.n_dh = (int)(((long)B * p.KP + 63) / 64);
+    rc = launch_finish(J, stream);
+    if (rc) return rc;
+  }
   return SCP_OK;
 }
