@@ -3,7 +3,8 @@ tools/make_goldens.py) against scpair_amd on the same synthetic inputs, seeds an
 
 Tolerances:
   fp32 path : per-step training loss rel 2e-4, per-epoch validation loss rel 2e-4, embeddings max-abs 2e-3
-  bf16 path : losses rel 2e-2, embeddings cosine median >= 0.999 and min >= 0.99 (8-dim toy embeddings)
+  bf16 path : losses rel 2e-2, embeddings cosine median >= 0.999, 5th percentile >= 0.99 and min >= 0.99 (0.95 with
+              BatchNorm; 8-dim toy embeddings)
 """
 import numpy as np
 import pytest
@@ -92,8 +93,9 @@ def test_trajectory_fp32(name):
             assert np.array_equal(np.take_along_axis(v, top[k]["indices"], 1), tv.numpy()), k
 
 
-def test_trajectory_bf16():
-    d, c, obj = _run("traj_nb_ber", "bf16")
+@pytest.mark.parametrize("name", ["traj_nb_ber", "traj_zinb_ber", "traj_nb_ber_bn"])
+def test_trajectory_bf16(name):
+    d, c, obj = _run(name, "bf16")
     names = list(c["modalities"].keys())
     for di in range(2):
         h = obj.history[names[di] + " to " + names[1 - di]]
@@ -103,7 +105,11 @@ def test_trajectory_bf16():
     for k, v in emb.items():
         g = torch.tensor(d["emb/" + k])
         cos = torch.nn.functional.cosine_similarity(v, g, dim=1)
-        assert float(cos.median()) > 0.999 and float(cos.min()) > 0.99, (k, float(cos.median()), float(cos.min()))
+        # BatchNorm (batch statistics of bf16-rounded activations) widens the tail: a few of the 8-dim toy embeddings
+        # land at 0.96-0.97; 5th percentile and median stay where the other configurations are
+        floor = 0.95 if name == "traj_nb_ber_bn" else 0.99
+        assert float(cos.median()) > 0.999 and float(cos.quantile(0.05)) > 0.99 and float(cos.min()) > floor, \
+            (k, float(cos.median()), float(cos.quantile(0.05)), float(cos.min()))
     S.set_precision("fp32")
 
 
@@ -147,8 +153,10 @@ def test_vae_trajectory_fp32():
         assert float((v.cpu() - torch.tensor(d["enc_final/" + k])).abs().max()) < 2e-3, k
 
 
-def test_vae_trainer_replays_reference_trajectory():
-    """scVAE_object (the package's epoch loop around train_VAE / eval_VAE, shaped like model.py:727-799) replaying the
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_vae_trainer_replays_reference_trajectory(precision):
+    """(precision 'bf16': same replay with bf16 MFMA operands; losses within 2e-2, weights within 2e-2 of their scale.)
+    scVAE_object (the package's epoch loop around train_VAE / eval_VAE, shaped like model.py:727-799) replaying the
     reference's recorded VAE run: same initial weights, batch order and noise stream -> per-epoch validation
     (total, reconstruction, KL) within 5e-4 relative and final encoder weights within 2e-3."""
     d = U.load("traj_vae_nb")
@@ -156,7 +164,9 @@ def test_vae_trainer_replays_reference_trajectory():
     rna = synth.make_rna(c["n"], c["g"], seed=c["seed"])
     obj = S.scVAE_object(distribution="nb", SEED=0, hidden_dim=c["hid"], latent_dim=c["L"], dropout_rate=0, batch_size=c["batch"],
                          L2_lambda=1e-9, max_epochs=c["epochs"], kl_weight=c["kl_weight"], device=DEV, sample_factor=True,
-                         infer_library_size=False, verbose=False, weight_decay_groups=False)
+                         infer_library_size=False, verbose=False, weight_decay_groups=False,
+                         use_mixed_precision=(precision == "bf16"))
+    ltol, wtol = (5e-4, 2e-3) if precision == "fp32" else (2e-2, None)
     eps_all = torch.tensor(d["eps"]).to(DEV)
     pos = [0]
 
@@ -178,13 +188,16 @@ def test_vae_trainer_replays_reference_trajectory():
     assert pos[0] == eps_all.numel()
     got = np.stack([obj.history["val_loss"], obj.history["val_recon"], obj.history["val_kl"]], 1)
     assert got.shape == d["eval"].shape
-    assert np.max(np.abs(got - d["eval"]) / np.abs(d["eval"])) < 5e-4, (got, d["eval"])
+    assert np.max(np.abs(got - d["eval"]) / np.abs(d["eval"])) < ltol, (got, d["eval"])
     for k, v in obj.last_encoder.state_dict().items():
-        assert float((v.cpu() - torch.tensor(d["enc_final/" + k])).abs().max()) < 2e-3, k
+        ref = torch.tensor(d["enc_final/" + k])
+        tol = wtol if wtol is not None else 2e-2 * max(float(ref.abs().max()), 1e-3)
+        assert float((v.cpu() - ref).abs().max()) < tol, k
     assert len(obj.history["train_loss"]) == len(d["batch_sizes"])
     obj.encoder.eps_source = None                      # the recorded noise stream is used up
     emb = obj.embeddings(rna)
     assert emb.shape == (c["n"], c["L"]) and bool(torch.isfinite(emb).all())
+    S.set_precision("fp32")
 
 
 def test_run_from_anndata_like_object():
