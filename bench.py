@@ -55,6 +55,8 @@ def parse():
                     help="N = 1: replay the step as one HIP graph (scpair_amd.graph.CapturedStep) instead of issuing every "
                          "launch from the host.  Off by default: on ROCm 7.2 a graph with two forked streams is replayed "
                          "node by node at the eager host cost, and the linear (one stream) replay took a box down")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="build each minibatch's tile lists at the start of its own step instead of during the previous one")
     ap.add_argument("--roofline-steps", type=int, default=20,
                     help="untimed single-stream steps after the timed region whose per-launch HIP events give roofline.achieved")
     return ap.parse_args()
@@ -216,7 +218,7 @@ def main():
         state["cur"] += a.batch
         return rows, rows_dev
 
-    def both_directions(t_rna, t_atac, time_adam, side):
+    def both_directions(t_rna, t_atac, time_adam, side, prefetch=None):
         if side is None:
             la = one_direction(A, t_rna, t_atac, time_adam)
             finish_direction(A, time_adam)
@@ -236,17 +238,31 @@ def main():
             with torch.cuda.stream(st):
                 out.append(one_direction(D, tx, ty, time_adam))
                 finish_direction(D, time_adam)
+        if prefetch is not None:
+            prefetch()      # the next minibatch's tile lists are built on this (otherwise idle) stream meanwhile
         for st in side:
             cur.wait_stream(st)
         return out[0], out[1]
 
-    def step(time_adam=False, side_=None):
+    def build_tiles():
         rows, rows_dev = next_rows()
         t0_ = pc()
         t_rna = S.BatchTiles(rna, rows_dev, want_lib=True, rows_host=rows)
         t_atac = S.BatchTiles(atac, rows_dev, want_lib=False, rows_host=rows)
         host_t["tiles"] += pc() - t0_
-        return both_directions(t_rna, t_atac, time_adam, side_)
+        return t_rna, t_atac
+
+    def step(time_adam=False, side_=None):
+        # Two streams: the tile lists of the NEXT minibatch (the data-loader stage: row ids -> tile lists, no weights
+        # involved) are built while this step's two directions run, as a prefetching loader would.
+        nxt = state.pop("next_tiles", None)
+        t_rna, t_atac = nxt if nxt is not None else build_tiles()
+        if side_ is None or a.no_prefetch:
+            return both_directions(t_rna, t_atac, time_adam, side_)
+
+        def prefetch():
+            state["next_tiles"] = build_tiles()
+        return both_directions(t_rna, t_atac, time_adam, side_, prefetch)
 
     side = (torch.cuda.Stream(), torch.cuda.Stream()) if a.streams == 2 else None
 
