@@ -20,6 +20,7 @@
 //     pass LOSS  : log-likelihood sum, T_row = sum_j (dll/dmu_j * mu_j)
 //     pass GRAD  : dZ -> dW, dh, db (+ feature_scalar / feature-dispersion gradients)
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "scpair_hip.h"
 
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   // Staging map of a 64 x KP operand block: thread -> (row sp = tid/4, columns [sq*KQ, sq*KQ + KQ)); one base
   // address per operand and immediate offsets keep the address arithmetic out of the register file.
   constexpr int KQ = KP / 4;
+  // the training passes sit at the register cap of 2 waves / SIMD: the clamped-address form of the operand loads
+  // (a few more address registers) spills there, so they keep predicated loads
+  constexpr bool UNPRED = !TRAIN;
   constexpr int EPF = 2;                        // label entries prefetched per thread
   const int sp = tid >> 2, sq = tid & 3;
   const bool vec_w = ((g.K & 3) == 0) && ((g.ldw & 3) == 0) && ((((uintptr_t)g.W) & 15) == 0);
@@ -128,7 +132,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   auto load_rows = [&](float* reg, const float* base, long ld, int row, int nrows, bool vec) {
     const float* src = base + (long)row * ld + sq * KQ;
     const bool rok = row < nrows;
-    if (vec) {
+    if (vec && UNPRED) {
+      // unpredicated: a row / column past the end reads a clamped (valid) address and put_rows zeroes what needs
+      // zeroing -- predicated loads cost an exec-mask save / restore and a skip branch each (K % 4 == 0 here); a
+      // select right here would wait for the load at issue time
+      const float* srow = base + (long)min(row, nrows - 1) * ld;
+#pragma unroll
+      for (int i = 0; i < KQ / 4; i++) {
+        const int col = sq * KQ + 4 * i;
+        const float4 t = *(const float4*)(srow + min(col, g.K - 4));
+        reg[4 * i] = t.x; reg[4 * i + 1] = t.y; reg[4 * i + 2] = t.z; reg[4 * i + 3] = t.w;
+      }
+    } else if (vec) {
 #pragma unroll
       for (int i = 0; i < KQ / 4; i++) {
         float4 v = {0.f, 0.f, 0.f, 0.f};
@@ -143,10 +158,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   auto load_w = [&](int f0n) { load_rows(wreg, g.W, g.ldw, f0n + sp, g.F, vec_w); };
   auto load_h = [&](int c0n) { load_rows(hreg, g.h, g.ldh, c0n + sp, g.B, vec_h); };
   // registers -> row-major image [NS][64][LDK_] (8-byte stores) and, when training, the transposed image [NS][KP][LDZ]
-  auto put_rows = [&](const float* reg, __bf16* img, __bf16* imgT) {
+  // `mask`: chunk validity (h block, once per cell block) or -1.  The W tile is staged unmasked: its clamped loads
+  // return real (finite) weights for the K-padding columns and for rows past F, the former meet the zeroed padding of
+  // h in every product and the latter only reach outputs that are masked (f < F) -- 36 selects per tile saved.
+  auto put_rows = [&](const float* reg, auto masked_c, bool vec, bool rok, __bf16* img, __bf16* imgT) {
     __bf16 tt[KQ][3];
+    if constexpr (!decltype(masked_c)::value) {
 #pragma unroll
-    for (int i = 0; i < KQ; i++) bf16_split<NS>(reg[i], tt[i]);
+      for (int i = 0; i < KQ; i++) bf16_split<NS>(reg[i], tt[i]);
+    } else {
+      // vector path: zero what the clamped loads returned for columns past K and rows past the end (the scalar path
+      // already loaded zeros there)
+#pragma unroll
+      for (int i = 0; i < KQ; i++) {
+        const bool keep = !(vec && UNPRED) || (rok && sq * KQ + (i & ~3) < g.K);
+        bf16_split<NS>(keep ? reg[i] : 0.f, tt[i]);
+      }
+    }
 #pragma unroll
     for (int s2 = 0; s2 < NS; s2++) {
 #pragma unroll
@@ -171,9 +199,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     ep0 = pn0; ep1 = pn1;
 #pragma unroll
     for (int i = 0; i < EPF; i++) {
-      int e = ep0 + tid + 256 * i;
-      ekey[i] = (e < ep1) ? g.t_key[e] : -1;
-      evl[i] = (e < ep1 && g.t_val) ? g.t_val[e] : 1.f;
+      const int e = ep0 + tid + 256 * i;
+      if (UNPRED) {
+        const int ec = max(min(e, ep1 - 1), 0);   // clamped (the entry arrays hold at least one element): no predicated load
+        ekey[i] = g.t_key[ec];                      // validity is recomputed from (ep0, ep1) where the entry is used:
+        evl[i] = g.t_val ? g.t_val[ec] : 1.f;     // no use of the loaded value here (it would wait for the load)
+      } else {
+        ekey[i] = (e < ep1) ? g.t_key[e] : -1;
+        evl[i] = (e < ep1 && g.t_val) ? g.t_val[e] : 1.f;
+      }
     }
   };
   const int ntl = min(NPT, (g.F - f_chunk0 + FT - 1) / FT);     // valid feature tiles of this chunk (>= 1)
@@ -197,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     float racc0[16], racc1[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-      racc0[e] = (MODE == MODE_NB_STATS) ? -INFINITY : 0.f;
+      racc0[e] = 0.f;        // NB_STATS: running maximum, floored at 0 (a' = relu(z) sigmoid(fs) >= 0)
       racc1[e] = 0.f;
     }
 
@@ -211,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       __syncthreads();                            // previous iteration's readers are done
       if (t == 0) {
         // ---- h block (both layouts) and the per-cell inputs, from the prefetch registers ---------------
-        put_rows(hreg, hA, hT);
+        put_rows(hreg, std::integral_constant<bool, UNPRED>{}, vec_h, c0 + sp < g.B, hA, hT);
         if (tid < CB) {
           int c = c0 + tid;
           bool ok = c < g.B;
@@ -226,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         }
       }
       // ---- W tile (both layouts) from the prefetch registers, clear label tile ---------------------
-      put_rows(wreg, WB, WT);
+      put_rows(wreg, std::false_type{}, vec_w, true, WB, WT);
       if (NEED_LABELS) {
         float4 z4 = {0.f, 0.f, 0.f, 0.f};
         for (int idx = tid; idx < CB * FT / 4; idx += 256) ((float4*)ytile)[idx] = z4;
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         bool odd = false;
 #pragma unroll
         for (int i = 0; i < EPF; i++)
-          if (ekey[i] >= 0) {
+          if (UNPRED ? (ep0 + tid + 256 * i < ep1) : (ekey[i] >= 0)) {
             ytile[(ekey[i] & 63) * FT + ((ekey[i] >> 6) - f0)] = evl[i];
             odd |= !(evl[i] == 1.f);
           }
@@ -322,6 +356,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
           dfs_acc[0] += su * (1.f - fcol);
           db_acc[0] += sd;
         }
+      } else if (MODE == MODE_NB_LOSS && (f0 + FT <= g.F) && (c0 + CB <= g.B)) {
+        // NB likelihood pass, interior tile.  Phase 1 treats every label as 0 in straight-line code (the transcendental
+        // chains of a group of elements interleave); phase 2 adds the terms of the non-zero labels (data-dependent
+        // loops).  Same algebra as the general loop below.  (The GRAD pass keeps the general loop: the same split
+        // spills there, its register budget is spent on the dW / dh accumulators.)
+        const float eps = 1e-8f;
+        constexpr int EH = 8;                         // elements per group
+#pragma unroll
+        for (int e0 = 0; e0 < 16; e0 += EH) {
+          __builtin_amdgcn_sched_barrier(0);          // keep the groups apart: interleaving all 16 chains spills
+          float mu_[EH], rs_[EH], ls_[EH];            // ls = log(theta + mu + eps)
+#pragma unroll
+          for (int j = 0; j < EH; j++) {
+            const int e = e0 + j;
+            const int cl = ti * 32 + acc_row(e, lane);
+            const float zz = acc[e] + bcol;
+            const float a_ = fmaxf(zz, 0.f);
+            const float ap = a_ * fcol;
+            const float L = rowv[cl], lse = rowv[CB + cl];
+            const float scale = exp_<FAST>(ap - lse);
+            const float mu = L * scale;
+            const float th = g.theta_param ? thcol : exp_<FAST>(a_);
+            const float s_ = th + mu + eps;
+            const float lt = log_<FAST>(th + eps), ls = log_<FAST>(s_);
+            const float rs = div_<FAST>(1.f, s_);
+            const float gmu = -th * rs;
+            mu_[j] = mu;
+            rs_[j] = rs;
+            lsum -= th * (lt - ls);
+            racc0[e] += gmu * mu;
+            ls_[j] = ls;
+          }
+#pragma unroll
+          for (int j = 0; j < EH; j++) {
+            const int e = e0 + j;
+            const int cl = ti * 32 + acc_row(e, lane);
+            const float yv = ytile[cl * FT + fl];
+            if (yv > eps) {
+              const float th = g.theta_param ? thcol : exp_<FAST>(fmaxf(acc[e] + bcol, 0.f));
+              const float mu = mu_[j];
+              const float gnz = yv * (div_<FAST>(1.f, mu + eps) - rs_[j]);
+              lsum -= yv * (log_<FAST>(mu + eps) - ls_[j]) + lgam3<FAST>(yv, th);
+              racc0[e] += gnz * mu;
+            }
+          }
+        }
       } else
 #pragma unroll
       for (int e = 0; e < 16; e++) {
@@ -357,12 +437,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
           float a_ = fmaxf(zz, 0.f);
           float ap = a_ * fcol;
           if (MODE == MODE_NB_STATS) {
-            if (ok) {
-              float m_old = racc0[e];
-              float m_new = fmaxf(m_old, ap);
-              racc1[e] = racc1[e] * exp_<FAST>(m_old - m_new) + exp_<FAST>(ap - m_new);
-              racc0[e] = m_new;
-            }
+            // branch-free: an element outside the matrix leaves the maximum alone and adds 0
+            const float m_old = racc0[e];
+            const float m_new = fmaxf(m_old, ok ? ap : 0.f);
+            const float term = exp_<FAST>(ap - m_new);
+            racc1[e] = racc1[e] * exp_<FAST>(m_old - m_new) + (ok ? term : 0.f);
+            racc0[e] = m_new;
           } else if (ok) {
             const float eps = 1e-8f;
             float L = rowv[cl], lse = rowv[CB + cl];
