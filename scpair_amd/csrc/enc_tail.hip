@@ -168,28 +168,28 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
     gam[c] = *(const f4*)(m.g1 + ko[c]);
     bet[c] = *(const f4*)(m.be1 + ko[c]);
   }
-  // split-K slabs of the first-layer product, summed in ascending order; two slabs (2 x 4 x NCH loads) in flight
+  // split-K slabs of the first-layer product, summed in ascending order; four slabs of loads in flight
   {
     const float* base[ET_RW];
 #pragma unroll
     for (int r = 0; r < ET_RW; r++) base[r] = m.slabs + (long)rowc[r] * m.ld_slab;
     int sl = 0;
-    for (; sl + 2 <= m.nslab; sl += 2) {
-      f4 t[2][ET_RW][NCH];
+    for (; sl + 4 <= m.nslab; sl += 4) {
+      f4 t[4][ET_RW][NCH];
 #pragma unroll
-      for (int u = 0; u < 2; u++)
+      for (int u = 0; u < 4; u++)
 #pragma unroll
         for (int r = 0; r < ET_RW; r++)
 #pragma unroll
           for (int c = 0; c < NCH; c++) t[u][r][c] = *(const f4*)(base[r] + (long)(sl + u) * m.slab_stride + ko[c]);
 #pragma unroll
-      for (int u = 0; u < 2; u++)
+      for (int u = 0; u < 4; u++)
 #pragma unroll
         for (int r = 0; r < ET_RW; r++)
 #pragma unroll
           for (int c = 0; c < NCH; c++) v[r][c] += t[u][r][c];
     }
-    if (sl < m.nslab) {
+    for (; sl < m.nslab; sl++) {
       f4 t[ET_RW][NCH];
 #pragma unroll
       for (int r = 0; r < ET_RW; r++)
@@ -254,32 +254,44 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
     if (jb * ET_QN < H2) {                        // uniform
       const int jn = min(ET_QN, H2 - jb * ET_QN);
       float zk = 0.f;
-      // U rows of W2 per trip: their loads are issued together (the compiler does not unroll a loop of unknown trip
-      // count on request, and one row per trip exposes the full L2 latency forty times)
-      auto rows_of_w2 = [&](auto u_c, int jj) {
-        constexpr int U = decltype(u_c)::value;
-        f4 wr[U][NCH];
+      // Four rows of W2 per group, software-pipelined: the loads of the next group are in flight while this one is
+      // multiplied (the compiler does not unroll a loop of unknown trip count on request, and a group per trip with
+      // nothing in flight exposes the L2 latency ten times).  The row count is padded to a multiple of four with
+      // clamped (valid) row addresses: a padding row lands in no lane (jj + u >= QN) or in a lane that is masked below.
+      auto load4 = [&](f4 (&w)[4][NCH], int jj) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
+        for (int u = 0; u < 4; u++) {
+          const float* row = m.W2 + (long)min(jb * ET_QN + jj + u, H2 - 1) * H1;
 #pragma unroll
-          for (int c = 0; c < NCH; c++) wr[u][c] = *(const f4*)(m.W2 + (long)(jb * ET_QN + jj + u) * H1 + ko[c]);
+          for (int c = 0; c < NCH; c++) w[u][c] = *(const f4*)(row + ko[c]);
+        }
+      };
+      auto mul4 = [&](const f4 (&w)[4][NCH], int jj) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
+        for (int u = 0; u < 4; u++) {
           float p[ET_RW];
 #pragma unroll
           for (int r = 0; r < ET_RW; r++) {
-            f4 acc = a[r][0] * wr[u][0];          // a = 0 in masked lanes
+            f4 acc = a[r][0] * w[u][0];           // a = 0 in masked lanes
 #pragma unroll
-            for (int c = 1; c < NCH; c++) acc += a[r][c] * wr[u][c];
+            for (int c = 1; c < NCH; c++) acc += a[r][c] * w[u][c];
             p[r] = f4sum(acc);
           }
           const float k = reduce_rw<ET_RW>(p, lane);
           zk = (jj + u == q) ? k : zk;
         }
       };
-      int jj = 0;
-      for (; jj + 4 <= jn; jj += 4) rows_of_w2(std::integral_constant<int, 4>{}, jj);
-      for (; jj < jn; jj++) rows_of_w2(std::integral_constant<int, 1>{}, jj);
+      {
+        const int ng = (jn + 3) >> 2;             // groups of four rows
+        f4 wa[4][NCH], wb[4][NCH];
+        load4(wa, 0);
+        for (int gq = 0; gq < ng; gq += 2) {
+          load4(wb, 4 * min(gq + 1, ng - 1));
+          mul4(wa, 4 * gq);
+          load4(wa, 4 * min(gq + 2, ng - 1));
+          if (gq + 1 < ng) mul4(wb, 4 * (gq + 1));
+        }
+      }
       zr[jb] = zk;
     }
   }
@@ -471,6 +483,11 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
     }
   }
   // ---- wide part: gradient wrt a1: da[cell][k] = sum_j dz2[cell][j] W2[j][k] ------------------------------------
+  f4 xh[ET_RW][NCH];                              // saved x-hat of layer 1: loaded here, used after the W2 loop
+#pragma unroll
+  for (int r = 0; r < ET_RW; r++)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) xh[r][c] = *(const f4*)(m.xhat1 + (long)min(row0 + r, B - 1) * H1 + ko[c]);
   f4 da[ET_RW][NCH];
 #pragma unroll
   for (int r = 0; r < ET_RW; r++)
@@ -480,32 +497,41 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
   for (int jb = 0; jb < ET_RW; jb++) {
     if (jb * ET_QN < H2) {
       const int jn = min(ET_QN, H2 - jb * ET_QN);
-      auto rows_of_w2 = [&](auto u_c, int jj) {
-        constexpr int U = decltype(u_c)::value;
-        f4 wr[U][NCH];
+      // same pipeline as the forward kernel: groups of four rows of W2, the next group's loads in flight; padding rows
+      // carry dz2 = 0 (masked above)
+      auto load4 = [&](f4 (&w)[4][NCH], int jj) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
+        for (int u = 0; u < 4; u++) {
+          const float* row = m.W2 + (long)min(jb * ET_QN + jj + u, H2 - 1) * H1;
 #pragma unroll
-          for (int c = 0; c < NCH; c++) wr[u][c] = *(const f4*)(m.W2 + (long)(jb * ET_QN + jj + u) * H1 + ko[c]);
+          for (int c = 0; c < NCH; c++) w[u][c] = *(const f4*)(row + ko[c]);
+        }
+      };
+      auto mul4 = [&](const f4 (&w)[4][NCH], int jj) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
+        for (int u = 0; u < 4; u++)
 #pragma unroll
           for (int r = 0; r < ET_RW; r++) {
             const float dzj = lane_bcast(d2[jb], r + ET_RW * (jj + u));   // dz2[cell r][QN jb + jj + u]
 #pragma unroll
-            for (int c = 0; c < NCH; c++) da[r][c] += dzj * wr[u][c];
+            for (int c = 0; c < NCH; c++) da[r][c] += dzj * w[u][c];
           }
       };
-      int jj = 0;
-      for (; jj + 4 <= jn; jj += 4) rows_of_w2(std::integral_constant<int, 4>{}, jj);
-      for (; jj < jn; jj++) rows_of_w2(std::integral_constant<int, 1>{}, jj);
+      const int ng = (jn + 3) >> 2;
+      f4 wa[4][NCH], wb[4][NCH];
+      load4(wa, 0);
+      for (int gq = 0; gq < ng; gq += 2) {
+        load4(wb, 4 * min(gq + 1, ng - 1));
+        mul4(wa, 4 * gq);
+        load4(wa, 4 * min(gq + 2, ng - 1));
+        if (gq + 1 < ng) mul4(wb, 4 * (gq + 1));
+      }
     }
   }
   // LayerNorm 1 / activation / dropout backward; column sums over the wave's cells stay in registers
   f4 sg[NCH], sb[NCH], sd[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; c++) sg[c] = sb[c] = sd[c] = zero4;
-  f4 xh[ET_RW][NCH];
   float t1p[ET_RW], t2p[ET_RW];
 #pragma unroll
   for (int r = 0; r < ET_RW; r++) {
@@ -513,7 +539,7 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      const f4 xl = *(const f4*)(m.xhat1 + (long)row * H1 + ko[c]);
+      const f4 xl = xh[r][c];
       const f4 z = xl * gam[c] + bet[c];
       const f4 dzl = dleaky4(z, da[r][c] * keep4(sd1, (uint64_t)row * H1 + ko[c], m.p1), m.slope);
       const f4 dz1 = ok[c] ? dzl : zero4;          // dead cells: dz2 = 0, hence da = 0 and dz1 = 0
