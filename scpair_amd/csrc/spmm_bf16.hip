@@ -11,6 +11,7 @@
 //   * the next K-step's dense tile and sparse entries are prefetched into registers while the MFMAs of the
 //     current step run.
 // The sparse operand is densified into LDS from the minibatch tile list exactly as in gemm.hip.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "scpair_hip.h"
@@ -535,6 +536,265 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// wgrad, narrow variant: tile 128 hidden x 128 features x 64 cells, 4 waves as 2 (hidden) x 2 (features), 74 KB of
+// LDS -> TWO workgroups per CU, so the HBM-bound AdamW epilogue of one overlaps the MFMA-bound K loop of the other
+// (the 256-feature kernel above fills the LDS with one workgroup and alternates the two phases).  Two X buffers
+// instead of three: the buffer step i+1 scatters into still holds step i-1, so a step is
+//     un-scatter(i-1) | barrier | stage(i+1), MFMAs(i), prefetch(i+4) | barrier.
+// ------------------------------------------------------------------------------------------------------
+template <bool HASVAL, bool ADAM, bool OUT16 = false, int EPB = 16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void spmm_dw128_bf16_kernel(SpArgs g) {
+  constexpr int EPT = HASVAL ? 4 : 2;             // sparse entries held per thread and stage
+  constexpr int ASZ = 128 * LDK, BSZ = 128 * LDK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* Bs = (__bf16*)smem_raw;        // [2][128][LDK]   X tile    [feature][cell]
+  __bf16* As = Bs + 2 * BSZ;             // [2][128][LDK]   dYT tile  [hidden][cell]
+  int* ptrs = (int*)(As + 2 * ASZ);      // [2][PCH + 1]: entry range [start, end) of this feature tile per cell block
+  __shared__ int ovf[3];                 // step+1 of a step whose X buffer holds entries beyond the per-thread slots
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, hq = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  int b = blockIdx.x;
+  int xcd = b & 7, j = b >> 3;
+  int m_tile = j % g.tiles_m;
+  int unit = (j / g.tiles_m) * 8 + xcd;
+  if (unit >= g.tiles_n) return;
+  const int m0 = m_tile * 128, n0 = unit * 128;
+  const int nend = min(n0 + 128, g.F);
+  const int nstep = g.ncb;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][jj][e] = 0.f;
+
+  u32x4 areg[3][4];
+  uint32_t ekey[3][EPT], eval_[3][HASVAL ? EPT : 1];
+  int p0[3], p1[3];
+  int skey[3][EPT];                               // LDS offsets this thread scattered for step j (slot j%3), -1 = none
+  const int arow = tid >> 3, akc = tid & 7;       // dYT tile chunks of this thread: rows arow, +32, +64, +96
+
+  auto prefetch = [&](u32x4 (&ar)[4], uint32_t (&ek)[EPT], uint32_t (&ev)[HASVAL ? EPT : 1], int& q0, int& q1,
+                      int step) {
+    const int k0 = step * 64;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int m = min(m0 + arow + 32 * i, g.N - 1);
+      long k = min((long)k0 + akc * 8, g.ldd - 8);
+      ar[i] = *(const u32x4*)(g.D + (long)m * g.ldd + k);
+    }
+    q0 = ptrs[step];
+    q1 = ptrs[(PCH + 1) + step];
+    const int elast = max(q1 - 1, 0);
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      int e = min(q0 + tid + 256 * i, elast);
+      ek[i] = (uint32_t)g.key[e];
+      if constexpr (HASVAL) ev[i] = __float_as_uint(g.val[e]);
+    }
+  };
+  // registers of one stage -> LDS operands of `step`
+  auto stage_out = [&](const u32x4 (&ar)[4], const uint32_t (&ek)[EPT], const uint32_t (&ev)[HASVAL ? EPT : 1], int q0,
+                       int q1, int step, int (&sk)[EPT]) {
+    const int k0 = step * 64;
+    __bf16* Ad = As + (step & 1) * ASZ;
+    __bf16* Bd = Bs + (step & 1) * BSZ;
+    const bool kin = (long)k0 + akc * 8 < g.ldd;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      u32x4 v = ar[i];
+      if (!(kin && m0 + arow + 32 * i < g.N)) v = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)&Ad[(arow + 32 * i) * LDK + akc * 8] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      sk[i] = -1;
+      if (q0 + tid + 256 * i < q1) {
+        int key = (int)ek[i];
+        float v = 1.f;
+        if constexpr (HASVAL) v = __uint_as_float(ev[i]);
+        int off = ((key >> 6) - n0) * LDK + (key & 63);
+        Bd[off] = (__bf16)v;
+        sk[i] = off;
+      }
+    }
+    if (q0 + 256 * EPT < q1) {                    // overflow of a dense (cell block, feature tile): rare, uniform
+      if (tid == 0) ovf[step % 3] = step + 1;
+      for (int e = q0 + tid + 256 * EPT; e < q1; e += 256) {
+        int key = (int)gload_b32_sync(g.key + e);
+        float v = 1.f;
+        if constexpr (HASVAL) v = __uint_as_float(gload_b32_sync(g.val + e));
+        Bd[((key >> 6) - n0) * LDK + (key & 63)] = (__bf16)v;
+      }
+    }
+  };
+  auto zero_B = [&](int buf) {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4* q = (u32x4*)(Bs + buf * BSZ);
+    for (int i = tid; i < BSZ * 2 / 16; i += 256) q[i] = z;
+  };
+  // undo the scatter of `step` (whose MFMAs are done): its buffer is all zero again afterwards
+  auto unscatter = [&](int step, const int (&sk)[EPT]) {
+    __bf16* Bd = Bs + (step & 1) * BSZ;
+    // the tag was written barriers ago (when the step was staged) and its slot is next written by step + 3, so every
+    // thread reads the same value; a stale tag of step-3 never matches
+    if (ovf[step % 3] == step + 1) {
+      zero_B(step & 1);
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPT; i++)
+        if (sk[i] >= 0) Bd[sk[i]] = (__bf16)0.f;
+    }
+  };
+
+  // entry ranges of this feature tile in every cell block (ncb <= PCH + 1, checked by the host)
+  for (int i = tid; i < 2 * (PCH + 1); i += 256) {
+    int which = i / (PCH + 1), cbx = i % (PCH + 1);
+    ptrs[i] = (cbx < g.ncb) ? g.ptr[(long)cbx * g.F + (which ? nend : n0)] : 0;
+  }
+  zero_B(0);
+  zero_B(1);
+  if (tid < 3) ovf[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 3; s++)
+    if (s < nstep) prefetch(areg[s], ekey[s], eval_[s], p0[s], p1[s], s);
+  stage_out(areg[0], ekey[0], eval_[0], p0[0], p1[0], 0, skey[0]);
+  if (3 < nstep) prefetch(areg[0], ekey[0], eval_[0], p0[0], p1[0], 3);
+  __syncthreads();
+
+  // One K-step; FULL = steps i-1 .. i+4 all exist (straight-line body, see the forward kernel)
+  auto k_step = [&](auto full_c, auto s_c, int i) {
+    constexpr bool FULL = decltype(full_c)::value;
+    constexpr int s = decltype(s_c)::value;       // i % 3
+    constexpr int s1 = (s + 1) % 3, s2 = (s + 2) % 3;
+    // phase 1: the X buffer step i+1 is about to use still holds the entries of step i-1 (whose MFMAs are done)
+    if (FULL || (i >= 1 && i + 1 < nstep)) unscatter(i - 1, skey[s2]);
+    __syncthreads();
+    const __bf16* Ar = As + (i & 1) * ASZ;
+    const __bf16* Br = Bs + (i & 1) * BSZ;
+    bf16x8 af[4][2], bfr[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        af[kk][q] = *(const bf16x8*)&Ar[(wm * 64 + q * 32 + r) * LDK + kk * 16 + hq * 8];
+        bfr[kk][q] = *(const bf16x8*)&Br[(wn * 64 + q * 32 + r) * LDK + kk * 16 + hq * 8];
+      }
+    auto mfma_group = [&](int kk) {
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) acc[q][jj] = mfma32(af[kk][q], bfr[kk][jj], acc[q][jj]);
+    };
+    if (FULL || i + 1 < nstep) stage_out(areg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 1, skey[s1]);
+    mfma_group(0);
+    mfma_group(1);
+    if (FULL || i + 4 < nstep) prefetch(areg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 4);
+    mfma_group(2);
+    mfma_group(3);
+    __syncthreads();
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  int i = 0;
+  if (i < nstep) k_step(F_{}, S0{}, i++);
+  if (i < nstep) k_step(F_{}, S1{}, i++);
+  if (i < nstep) k_step(F_{}, S2{}, i++);
+  for (; i + 6 < nstep; i += 3) {
+    k_step(T_{}, S0{}, i);
+    k_step(T_{}, S1{}, i + 1);
+    k_step(T_{}, S2{}, i + 2);
+  }
+  for (; i < nstep; i += 3) {
+    k_step(F_{}, S0{}, i);
+    if (i + 1 < nstep) k_step(F_{}, S1{}, i + 1);
+    if (i + 2 < nstep) k_step(F_{}, S2{}, i + 2);
+  }
+
+  if constexpr (!ADAM) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) {
+        int n = n0 + wn * 64 + jj * 32 + r;
+        if (n >= g.F) continue;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          int m = m0 + wm * 64 + i2 * 32 + acc_row(e, lane);
+          if (m < g.N) {
+            if constexpr (OUT16) ((__bf16*)g.C)[(long)m * g.ldc + n] = (__bf16)acc[i2][jj][e];
+            else g.C[(long)m * g.ldc + n] = acc[i2][jj][e];
+          }
+        }
+      }
+  } else {
+    // gradient tile -> LDS [128][GLD] (all waves passed the last barrier of the K loop: the operand buffers are dead)
+    constexpr int GLD = 132;
+    float* gt = (float*)smem_raw;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+          gt[(wm * 64 + i2 * 32 + acc_row(e, lane)) * GLD + wn * 64 + jj * 32 + r] = acc[i2][jj][e];
+    __syncthreads();
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const float bc1 = g.bc_dev ? g.bc_dev[0] : g.bc1, bc2 = g.bc_dev ? g.bc_dev[1] : g.bc2;
+    const AdamHyper hy = adam_hyper(g.lr, g.wd, g.b1, g.b2, g.eps, bc1, bc2, g.gscale);
+    const int c4 = (tid & 31) * 4, rw = tid >> 5;   // half a wave per 512 B row segment, 8 rows per pass
+    const int n = n0 + c4;
+    const bool col_ok = n + 4 <= g.F;               // F % 4 == 0 (host-checked): a float4 is all in or all out
+#pragma unroll 1
+    for (int pass = 0; pass < 16; pass += EPB) {
+      // EPB row segments of the three streams in flight per lane before the first use: with one workgroup per CU the
+      // epilogue's HBM rate is set by the bytes each CU keeps outstanding
+      f4 pp[EPB], mm[EPB], vv[EPB];
+#pragma unroll
+      for (int u = 0; u < EPB; u++) {
+        int m = m0 + (pass + u) * 8 + rw;
+        if (col_ok && m < g.N) {
+          long o = (long)m * g.ldc + n;
+          pp[u] = __builtin_nontemporal_load((const f4*)(g.C + o));
+          mm[u] = __builtin_nontemporal_load((const f4*)(g.adam_m + o));
+          vv[u] = __builtin_nontemporal_load((const f4*)(g.adam_v + o));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < EPB; u++) {
+        int row = (pass + u) * 8 + rw;
+        int m = m0 + row;
+        if (col_ok && m < g.N) {
+          f4 gg = *(const f4*)&gt[row * GLD + c4];
+          float pa[4], ma[4], va[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            pa[k] = pp[u][k]; ma[k] = mm[u][k]; va[k] = vv[u][k];
+            adamw_update(hy, pa[k], gg[k], ma[k], va[k]);
+          }
+          long o = (long)m * g.ldc + n;
+          f4 po = {pa[0], pa[1], pa[2], pa[3]}, mo = {ma[0], ma[1], ma[2], ma[3]}, vo = {va[0], va[1], va[2], va[3]};
+          __builtin_nontemporal_store(po, (f4*)(g.C + o));
+          __builtin_nontemporal_store(mo, (f4*)(g.adam_m + o));
+          __builtin_nontemporal_store(vo, (f4*)(g.adam_v + o));
+          bf16x4 sh;
+#pragma unroll
+          for (int k = 0; k < 4; k++) sh[k] = (__bf16)pa[k];
+          *(bf16x4*)(g.adam_sh + (long)m * g.adam_ldsh + n) = sh;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // helpers: fp32 -> bf16 cast into a padded shadow, and fp32 [rows][cols] -> bf16 transposed [cols][ldt]
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, long rows, long cols, long lds_,
@@ -581,6 +841,20 @@ extern "C" int scp_transpose_bf16(const float* src, int rows, int cols, long ld_
 }
 
 static int set_smem(const void* fn, size_t smem, uint64_t* done) { return scp_set_smem(fn, smem, done); }
+
+// Feature-tile width of the fused weight-gradient + AdamW launch: 128 (two workgroups per CU) for implicit-ones
+// data, 256 (one workgroup per CU) for data with values -- measured at C2: 519 against 555 us for the 900 x 100 k
+// ATAC weights, 175 against 160 us for 900 x 20 k RNA weights (four value-carrying entries per thread and step
+// spill in the narrow variant).  SCPAIR_DW_TILE = 128 / 256 overrides.
+static int dw_tile_features(bool has_val) {
+  static int w = -1;
+  if (w < 0) {
+    const char* e = getenv("SCPAIR_DW_TILE");
+    w = e ? atoi(e) : 0;
+  }
+  if (w == 128 || w == 256) return w;
+  return has_val ? 256 : 128;
+}
 
 // smallest split-K factor scp_spmm_fwd_bf16 accepts for F features (its per-slab offset table holds PCH K-steps)
 extern "C" int scp_spmm_fwd_bf16_min_split(int F) {
@@ -678,6 +952,24 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
   g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_sh = (__bf16*)W_bf16; g.adam_ldsh = ld_bf16;
   g.lr = lr; g.wd = weight_decay; g.b1 = beta1; g.b2 = beta2; g.eps = eps; g.bc1 = bias_corr1; g.bc2 = bias_corr2;
   g.gscale = grad_scale; g.bc_dev = bc_dev;
+  if (dw_tile_features(t_val != nullptr) == 128) {
+    // two workgroups of 128 x 128 tiles per CU: the AdamW epilogue of one overlaps the K loop of the other
+    static uint64_t d128_v = 0, d128_n = 0;
+    const size_t smem128 = (size_t)(2 * 128 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
+    static_assert((size_t)128 * 132 * sizeof(float) <= (size_t)(2 * 128 + 2 * 128) * LDK * sizeof(__bf16),
+                  "gradient tile must fit in the operand buffers");
+    rc = t_val ? set_smem((const void*)spmm_dw128_bf16_kernel<true, true>, smem128, &d128_v)
+               : set_smem((const void*)spmm_dw128_bf16_kernel<false, true>, smem128, &d128_n);
+    if (rc) return rc;
+    g.tiles_n = (F + 127) / 128;
+    const int grid128 = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
+    if (t_val)
+      hipLaunchKernelGGL((spmm_dw128_bf16_kernel<true, true>), dim3(grid128), dim3(256), smem128, (hipStream_t)stream_, g);
+    else
+      hipLaunchKernelGGL((spmm_dw128_bf16_kernel<false, true>), dim3(grid128), dim3(256), smem128, (hipStream_t)stream_, g);
+    SCP_LAUNCH_CHECK();
+    return SCP_OK;
+  }
   int grid = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
   if (t_val)
     hipLaunchKernelGGL((spmm_dw_bf16_kernel<true, true>), dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
