@@ -383,10 +383,10 @@ def main():
         f_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in fused_ev)
         f_bytes = sum(26.0 * n + ob for _, _, n, ob in fused_ev)
         f_gbs = f_bytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
-        roof = {"kernel": "spmm_dw_bf16_kernel<*, ADAM> (first-layer weight gradient with the AdamW step in its epilogue)",
+        roof = {"kernel": "spmm_dw128_bf16_kernel / spmm_dw_bf16_kernel<*, ADAM> (first-layer weight gradient with the AdamW step in its epilogue; one launch per encoder)",
                 "bound": "hbm", "achieved": f_gbs, "peak": 8000.0, "unit": "GB/s", "frac": f_gbs / 8000.0,
-                "traffic": pmc_traffic("r01_dw_adamw_traffic.json", f_bytes / n_roof),
-                "traffic_source": "stored: profiles/r01_dw_adamw_traffic.json (separate rocprofv3 --pmc passes over this command)",
+                "traffic": pmc_traffic("r02_dw_adamw_traffic.json", f_bytes / n_roof),
+                "traffic_source": "stored: profiles/r02_dw_adamw_traffic.json (separate rocprofv3 --pmc passes over this command, round 2 kernels)",
                 "algorithmic_bytes_per_launch_set": f_bytes / n_roof,
                 "avg_ms_per_step_in_kernel": f_ms / n_roof,
                 "launches_per_step": len(fused_ev) / n_roof,
