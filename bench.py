@@ -93,14 +93,13 @@ class Direction:
 
     def n_trained_params(self):
         """Parameters that received an update in the last step (dead layers get no gradient and are skipped)."""
-        extra = {id(p) for p in self.first} if (self.fused or self.sink is not None) else set()
-        return sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None or id(p) in extra)
+        extra = sum(p.numel() for p in self.first) if self.fused else 0
+        return sum(self.opt.last_step_numel) + extra
 
     def adamw_kernel_bytes(self):
         """Algorithmic bytes of this direction's multi-tensor AdamW launch: 28 B/param, 26 where the
         gradient is read as bf16 from the exchange buffer; parameters updated inside their dW kernel are not in it."""
-        n32 = sum(p.numel() for g in self.opt.param_groups for p in g["params"] if p.grad is not None)
-        n16 = sum(p.numel() for p in self.first) if self.sink is not None else 0
+        n32, n16 = self.opt.last_step_numel
         return 28.0 * n32 + 26.0 * n16
 
 
@@ -203,11 +202,11 @@ def main():
         if time_adam:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            D.opt.step(grad_scale=1.0 / world)
+            D.opt.step(grad_scale=1.0 / world, release_grads=True)
             e1.record()
             adam_ev.append((e0, e1, D.adamw_kernel_bytes()))
         else:
-            D.opt.step(grad_scale=1.0 / world)
+            D.opt.step(grad_scale=1.0 / world, release_grads=True)
 
     def next_rows():
         if state["cur"] + a.batch > cells_here:

@@ -1225,6 +1225,12 @@ def fused_handle(W):
     return h
 
 
+import struct as _struct
+
+_ADAM_FMT = _struct.Struct("@PPPPqfffffPqqqP")     # ScpAdamTensor, packed without building ctypes objects per tensor
+assert _ADAM_FMT.size == C.sizeof(_lib.AdamTensor)
+
+
 class FusedAdamW(torch.optim.Optimizer):
     """Drop-in for torch.optim.AdamW as the reference configures it (model.py:698-701): same param_groups
     / state layout ('step', 'exp_avg', 'exp_avg_sq'), one fused multi-tensor HIP launch per step."""
@@ -1233,6 +1239,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._grads_released = False    # the last step() set every gradient it consumed to None
+        self.last_step_numel = (0, 0)
+        self._checked = {}              # id(p) -> data_ptr whose device / contiguity checks have passed
+        self._bufs = {}                 # (beta1, beta2, eps) -> bytearray of packed ScpAdamTensor descriptors
         self.step_state = None          # StepState while a step of this optimiser is being captured / replayed
         self._dyn_params = {}           # id(p) -> p: parameters the captured step updates
         self._dyn_betas = None
@@ -1298,61 +1308,103 @@ class FusedAdamW(torch.optim.Optimizer):
                         raise RuntimeError("unfuse: a fused update is pending, call step() first")
                     del _fused[id(p)]
 
+    def zero_grad(self, set_to_none: bool = True):
+        """torch's zero_grad(set_to_none=True) as a plain loop (the trainers call it right before every backward(),
+        40 parameters per predictor); after step(release_grads=True) it finds nothing to drop."""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    p.grad = None
+
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, release_grads: bool = False):
+        """One AdamW step on every parameter that has a gradient (or a written bf16 gradient sink).
+        release_grads: set the consumed `.grad`s to None afterwards, which makes the next zero_grad() free."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        fmt = _ADAM_FMT
         by_hyper = {}
         keep = []
+        dyn = self.step_state
+        checked = self._checked
+        released = release_grads
+        n32 = n16 = 0
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            lr, wd = group["lr"], group["weight_decay"]
+            key = (b1, b2, group["eps"])
             for p in group["params"]:
-                fz = _fused.get(id(p))
+                fz = _fused.get(id(p)) if _fused else None
                 if fz is not None and fz.pending and fz.opt is self and fz.param is p:
                     if grad_scale != 1.0:
                         raise RuntimeError("FusedAdamW: grad_scale is not available for weights updated during backward()")
                     if p.grad is not None:
                         raise RuntimeError("FusedAdamW: a weight updated during backward() also received a gradient")
-                    if self.step_state is None:
+                    if dyn is None:
                         self.state[p]["step"] += 1
                     fz.pending = False
                     continue
                 g16 = 0
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     sk = _sinks.get(id(p)) if _sinks else None
                     if sk is None or not sk.written or sk.param is not p:
                         continue
                     g, g16, sk.written = sk.view, 1, False      # bf16 gradient in the exchange buffer
-                else:
-                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                _lib.require_cuda(p)
-                if not p.is_contiguous():
-                    raise RuntimeError("FusedAdamW needs contiguous parameters")
+                elif not g.is_contiguous():
+                    g = g.contiguous()
+                pptr = p.data_ptr()
+                if checked.get(id(p)) != pptr:                  # device / layout checks once per (parameter, storage)
+                    _lib.require_cuda(p)
+                    if not p.is_contiguous():
+                        raise RuntimeError("FusedAdamW needs contiguous parameters")
+                    checked[id(p)] = pptr
                 st = self.state[p]
                 if len(st) == 0:
                     _new_adam_state(self, p)
-                dyn = self.step_state
                 if dyn is None:
-                    st["step"] += 1
-                    t = st["step"]
-                    bc1, bc2, bc_dev = 1 - b1 ** t, 1 - b2 ** t, None
+                    t = st["step"] = st["step"] + 1
+                    bc1, bc2, bc_dev = 1 - b1 ** t, 1 - b2 ** t, 0
                 else:                         # captured step: counters advance in dyn_advance(), once per replay
                     self._dyn_note(p, (b1, b2))
                     bc1, bc2, bc_dev = 1.0, 1.0, dyn.bc_ptr
                 sh = shadow_of(p, create=False) if p.ndim == 2 else None
-                d = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                    p.numel(), group["lr"], group["weight_decay"], bc1, bc2, grad_scale,
-                                    None if sh is None else sh.data_ptr(), p.shape[-1],
-                                    0 if sh is None else sh.shape[1], g16, bc_dev)
-                by_hyper.setdefault((b1, b2, group["eps"]), []).append(d)
+                ent = by_hyper.get(key)
+                if ent is None:
+                    ent = by_hyper[key] = [self._desc_buf(key), 0]
+                buf, n = ent
+                if (n + 1) * fmt.size > len(buf):
+                    buf.extend(bytes(len(buf)))
+                fmt.pack_into(buf, n * fmt.size, pptr, g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                              p.numel(), lr, wd, bc1, bc2, grad_scale, 0 if sh is None else sh.data_ptr(), p.shape[-1],
+                              0 if sh is None else sh.shape[1], g16, bc_dev)
+                ent[1] = n + 1
                 keep.append(g)
-        for (b1, b2, eps), descs in by_hyper.items():
-            arr = (_lib.AdamTensor * len(descs))(*descs)
-            _lib.check(L.scp_adamw_multi(arr, len(descs), b1, b2, eps, _lib.stream()), "scp_adamw_multi")
+                if g16:
+                    n16 += p.numel()
+                else:
+                    n32 += p.numel()
+                if released and not g16:
+                    p.grad = None
+        stream = _lib.stream()
+        for (b1, b2, eps), (buf, n) in by_hyper.items():
+            arr = (C.c_char * len(buf)).from_buffer(buf)
+            _lib.check(L.scp_adamw_multi(C.cast(arr, C.POINTER(_lib.AdamTensor)), n, b1, b2, eps, stream), "scp_adamw_multi")
+            del arr
+        self._grads_released = released
+        self.last_step_numel = (n32, n16)       # parameters stepped from fp32 / bf16 gradients by this call
         return loss
+
+    def _desc_buf(self, key):
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = bytearray(_ADAM_FMT.size * 64)
+        return b
 
 
 # ------------------------------------------------------------------------------------------------

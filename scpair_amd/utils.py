@@ -237,7 +237,10 @@ def train_net(input, output, library_size, encoder, decoder, optimizer, likeliho
                                     input_batch, output_batch)
     optimizer.zero_grad()
     ops.backward_root(training_loss)
-    optimizer.step()
+    if isinstance(optimizer, ops.FusedAdamW):
+        optimizer.step(release_grads=True)      # the next zero_grad() (40 parameters) becomes free
+    else:
+        optimizer.step()
     return training_loss.detach()
 
 
