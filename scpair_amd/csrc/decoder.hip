@@ -8,8 +8,23 @@ int dec_run_ber_ns3(int mode, const DecArgs& g, int kp, int grid, hipStream_t st
 int dec_run_nb_ns1(int mode, const DecArgs& g, int kp, int grid, hipStream_t stream);
 int dec_run_nb_ns3(int mode, const DecArgs& g, int kp, int grid, hipStream_t stream);
 
+#ifdef DEC_PROF
+static unsigned long long* prof_dev = nullptr;
+extern "C" int scp_dec_prof_read(unsigned long long* out, int n) {
+  if (!prof_dev) return -1;
+  hipDeviceSynchronize();
+  return (int)hipMemcpy(out, prof_dev, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
+}
+#endif
+
 template <int MODE>
-static int dec_dispatch(const DecArgs& g, int ns, int grid, hipStream_t stream) {
+static int dec_dispatch(const DecArgs& g_, int ns, int grid, hipStream_t stream) {
+  DecArgs g = g_;
+#ifdef DEC_PROF
+  if (!prof_dev) { hipMalloc(&prof_dev, sizeof(unsigned long long) * 12 * 4096); }
+  hipMemsetAsync(prof_dev, 0, sizeof(unsigned long long) * 12 * 4096, stream);
+  g.prof = prof_dev;
+#endif
   SCP_CHECK(g.K <= 64, SCP_ERR_SHAPE, "decoder: latent+covariate width K=%d > 64 unsupported", g.K);
   int kp = g.K <= 16 ? 16 : (g.K <= 48 ? 48 : 64);
   SCP_CHECK(!(ns == 3 && kp == 64), SCP_ERR_SHAPE, "decoder: K=%d > 48 needs ns = 1 (LDS budget)", g.K);
@@ -57,7 +72,7 @@ __global__ __launch_bounds__(1024) void dec_finish_all_kernel(FinishJobs J) {
   if (blk < J.n_dh) {
     const long j = (long)blk * 64 + x;   // b * KP + k
     const bool ok = j < (long)J.B * J.KP;
-    const float s = ok ? strided_sum16(J.dh_slab + j, (long)J.B * J.KP, J.nchunk, y) : 0.f;
+    const float s = ok ? strided_sum16(J.dh_slab + j, (long)((J.B + CB - 1) / CB * CB) * J.KP, J.nchunk, y) : 0.f;
     red[0][y][x] = s;
     __syncthreads();
     if (y == 0 && ok) {
@@ -188,10 +203,11 @@ static int check_common(const char* who, int B, int F, int K, const float* h, co
 
 // Workspace layout, nchunk = scp_dec_chunks(F), KP = scp_dec_kp(K), ncg = cell groups:
 //   ws_d : doubles [nchunk*ncg + 8]
-//   ws_f : floats  [nchunk*B*KP] dh slabs | [nchunk*B*2] row slabs | [ncg*F*K] dW slabs | [3*ncg*F] db/dfs/dtheta slabs
+//   ws_f : floats  [nchunk*Bp*KP] dh slabs (Bp = B rounded up to whole 64-cell blocks) | [nchunk*B*2] row slabs | [ncg*F*K] dW slabs | [3*ncg*F] db/dfs/dtheta slabs
 extern "C" long scp_dec_ws_floats(int B, int F, int K) {
   long nchunk = scp_dec_chunks(F), ncg = dec_ncg(B, F);
-  return nchunk * (long)B * scp_dec_kp(K) + nchunk * (long)B * 2 + ncg * (long)F * K + 3 * ncg * (long)F;
+  const long Bp = (B + CB - 1) / CB * CB;
+  return nchunk * Bp * scp_dec_kp(K) + nchunk * (long)B * 2 + ncg * (long)F * K + 3 * ncg * (long)F;
 }
 extern "C" long scp_dec_ws_doubles(int B, int F) { return (long)scp_dec_chunks(F) * dec_ncg(B, F) + 8; }
 
@@ -204,7 +220,7 @@ static DecPlan make_plan(DecArgs& g, float* ws_f, float* dW, long lddw, float* d
   DecPlan p;
   p.nchunk = scp_dec_chunks(g.F); p.KP = scp_dec_kp(g.K); p.cpg = dec_cpg(g.B, g.F); p.ncg = dec_ncg(g.B, g.F);
   p.dh_slab = ws_f;
-  p.row_slab = ws_f ? p.dh_slab + (long)p.nchunk * g.B * p.KP : nullptr;
+  p.row_slab = ws_f ? p.dh_slab + (long)p.nchunk * ((g.B + CB - 1) / CB * CB) * p.KP : nullptr;
   p.dW_slab = ws_f ? p.row_slab + (long)p.nchunk * g.B * 2 : nullptr;
   p.db_slab = ws_f ? p.dW_slab + (long)p.ncg * g.F * g.K : nullptr;
   p.dfs_slab = ws_f ? p.db_slab + (long)p.ncg * g.F : nullptr;

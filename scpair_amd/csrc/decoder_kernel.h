@@ -56,7 +56,16 @@ struct DecArgs {
   // dW + y*cg_stride_w, db/dfs/dtheta + y*F (summed by the finishing kernels when ncg > 1)
   int cpg;
   long cg_stride_w;
+#ifdef DEC_PROF
+  unsigned long long* prof;    // diagnostic build only: per-phase timestamps of one wave
+#endif
 };
+
+#ifdef DEC_PROF
+#define PROF_MARK(m) do { if (prof_on) g.prof[prof_it * 12 + (m)] = clock64(); } while (0)
+#else
+#define PROF_MARK(m) do { } while (0)
+#endif
 
 template <int NS>
 __device__ __forceinline__ void img_put(__bf16* img, int rows, int ld, int row, int col, float v) {
@@ -66,7 +75,7 @@ __device__ __forceinline__ void img_put(__bf16* img, int rows, int ld, int row, 
   for (int s = 0; s < NS; s++) img[(s * rows + row) * ld + col] = t[s];
 }
 
-template <int NS, int KP, int NPT, int MODE>
+template <int NS, int KP, int NPT, int MODE, bool VEC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dec_kernel(DecArgs g) {
   constexpr bool IS_BER = (MODE == MODE_BER_TRAIN || MODE == MODE_BER_EVAL);
   constexpr bool TRAIN = (MODE == MODE_BER_TRAIN || MODE == MODE_NB_GRAD);
@@ -117,64 +126,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   // Staging map of a 64 x KP operand block: thread -> (row sp = tid/4, columns [sq*KQ, sq*KQ + KQ)); one base
   // address per operand and immediate offsets keep the address arithmetic out of the register file.
   constexpr int KQ = KP / 4;
-  // the training passes sit at the register cap of 2 waves / SIMD: the clamped-address form of the operand loads
-  // (a few more address registers) spills there, so they keep predicated loads
-  constexpr bool UNPRED = !TRAIN;
   constexpr int EPF = 2;                        // label entries prefetched per thread
   const int sp = tid >> 2, sq = tid & 3;
-  const bool vec_w = ((g.K & 3) == 0) && ((g.ldw & 3) == 0) && ((((uintptr_t)g.W) & 15) == 0);
-  const bool vec_h = ((g.K & 3) == 0) && ((g.ldh & 3) == 0) && ((((uintptr_t)g.h) & 15) == 0);
+  // VEC (chosen by the host: K and the leading dimensions multiples of 4, 16-byte aligned bases, operands below 1 GiB):
+  // the operand blocks come in through raw buffer loads.  The hardware range check returns zeros for rows past the
+  // end, and a per-thread column offset that is either the chunk's byte offset or a value past every buffer does the
+  // same for the K-padding columns -- no predication, no branches, 32-bit offsets.  Otherwise: scalar predicated loads.
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, VEC ? (int)(((long)(g.F - 1) * g.ldw + g.K) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_h =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.h, 0, VEC ? (int)(((long)(g.B - 1) * g.ldh + g.K) * 4) : 0, 0x00020000);
+  int coff[KQ / 4];
+#pragma unroll
+  for (int i = 0; i < KQ / 4; i++) coff[i] = (sq * KQ + 4 * i < g.K) ? (sq * KQ + 4 * i) * 4 : (1 << 30);
   float wreg[KQ], hreg[KQ];
   int ekey[EPF];
   float evl[EPF];
+  // implicit-ones data (t_val == null): the value loads read the key words instead and the result is ignored where the
+  // entry is used -- a branch around the loads would end in register copies that wait for every load in flight
+  const float* e_val = g.t_val ? g.t_val : (const float*)g.t_key;
   int ep0 = 0, ep1 = 0;                         // entry range of the upcoming iteration
   int pn0 = 0, pn1 = 0;                         // entry range of the iteration after it (ptr loaded one step earlier)
-  auto load_rows = [&](float* reg, const float* base, long ld, int row, int nrows, bool vec) {
-    const float* src = base + (long)row * ld + sq * KQ;
-    const bool rok = row < nrows;
-    if (vec && UNPRED) {
-      // unpredicated: a row / column past the end reads a clamped (valid) address and put_rows zeroes what needs
-      // zeroing -- predicated loads cost an exec-mask save / restore and a skip branch each (K % 4 == 0 here); a
-      // select right here would wait for the load at issue time
-      const float* srow = base + (long)min(row, nrows - 1) * ld;
+  auto load_rows = [&](float* reg, const float* base, long ld, int row, int nrows, __amdgpu_buffer_rsrc_t rsrc) {
+    if constexpr (VEC) {
+      const int roff = row * (int)ld * 4;
 #pragma unroll
       for (int i = 0; i < KQ / 4; i++) {
-        const int col = sq * KQ + 4 * i;
-        const float4 t = *(const float4*)(srow + min(col, g.K - 4));
+        const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, roff + coff[i], 0, 0));
         reg[4 * i] = t.x; reg[4 * i + 1] = t.y; reg[4 * i + 2] = t.z; reg[4 * i + 3] = t.w;
       }
-    } else if (vec) {
-#pragma unroll
-      for (int i = 0; i < KQ / 4; i++) {
-        float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (rok && sq * KQ + 4 * i < g.K) v = *(const float4*)(src + 4 * i);
-        reg[4 * i] = v.x; reg[4 * i + 1] = v.y; reg[4 * i + 2] = v.z; reg[4 * i + 3] = v.w;
-      }
     } else {
+      const float* src = base + (long)row * ld + sq * KQ;
+      const bool rok = row < nrows;
 #pragma unroll
       for (int i = 0; i < KQ; i++) reg[i] = (rok && sq * KQ + i < g.K) ? src[i] : 0.f;
     }
   };
-  auto load_w = [&](int f0n) { load_rows(wreg, g.W, g.ldw, f0n + sp, g.F, vec_w); };
-  auto load_h = [&](int c0n) { load_rows(hreg, g.h, g.ldh, c0n + sp, g.B, vec_h); };
-  // registers -> row-major image [NS][64][LDK_] (8-byte stores) and, when training, the transposed image [NS][KP][LDZ]
-  // `mask`: chunk validity (h block, once per cell block) or -1.  The W tile is staged unmasked: its clamped loads
-  // return real (finite) weights for the K-padding columns and for rows past F, the former meet the zeroed padding of
-  // h in every product and the latter only reach outputs that are masked (f < F) -- 36 selects per tile saved.
-  auto put_rows = [&](const float* reg, auto masked_c, bool vec, bool rok, __bf16* img, __bf16* imgT) {
+  // The per-feature scalars of a tile (bias, feature_scalar, log theta) and the per-cell inputs of a block travel with
+  // the operand prefetch: loaded where they are used, they would wait for every prefetch load issued before them
+  // (loads return in order), once per iteration.  Indices are clamped instead of predicated.
+  float bias_n = 0.f, fs_n = 0.f, th_n = 0.f;      // upcoming tile, feature tj*32 + r
+  float row_n[3] = {0.f, 0.f, 0.f};                // upcoming block, cell (tid & 63): lrow | rowlse | rowT
+  auto load_w = [&](int f0n) {
+    load_rows(wreg, g.W, g.ldw, f0n + sp, g.F, rsrc_w);
+    const int fc = min(f0n + (wave & 1) * 32 + (lane & 31), g.F - 1);
+    bias_n = g.bias[fc];
+    if (g.fs) fs_n = g.fs[fc];
+    if (!IS_BER && g.theta_param) th_n = g.theta_param[fc];
+  };
+  auto load_h = [&](int c0n) {
+    load_rows(hreg, g.h, g.ldh, c0n + sp, g.B, rsrc_h);
+    const int cc = min(c0n + lane, g.B - 1);
+    if (g.lrow) row_n[0] = g.lrow[g.lrow_n == 1 ? 0 : cc];
+    if (!IS_BER && MODE != MODE_NB_STATS && g.rowlse) row_n[1] = g.rowlse[cc];
+    if (MODE == MODE_NB_GRAD && g.rowT) row_n[2] = g.rowT[cc];
+  };
+  // registers -> row-major image [NS][64][LDK_] (8-byte stores) and, when training, the transposed image [NS][KP][LDZ];
+  // rows past the end and the K-padding columns arrive as zeros from either load path
+  auto put_rows = [&](const float* reg, __bf16* img, __bf16* imgT) {
     __bf16 tt[KQ][3];
-    if constexpr (!decltype(masked_c)::value) {
 #pragma unroll
-      for (int i = 0; i < KQ; i++) bf16_split<NS>(reg[i], tt[i]);
-    } else {
-      // vector path: zero what the clamped loads returned for columns past K and rows past the end (the scalar path
-      // already loaded zeros there)
-#pragma unroll
-      for (int i = 0; i < KQ; i++) {
-        const bool keep = !(vec && UNPRED) || (rok && sq * KQ + (i & ~3) < g.K);
-        bf16_split<NS>(keep ? reg[i] : 0.f, tt[i]);
-      }
-    }
+    for (int i = 0; i < KQ; i++) bf16_split<NS>(reg[i], tt[i]);
 #pragma unroll
     for (int s2 = 0; s2 < NS; s2++) {
 #pragma unroll
@@ -190,8 +202,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       }
     }
   };
+  // The tile-range words are uniform, and a uniform address makes these scalar loads: scalar loads share their counter
+  // with LDS traffic, so the wait in front of the next barrier would expose their full latency (a miss every time,
+  // the range array is large) once per iteration.  An opaque per-lane zero keeps them vector loads (counted with the
+  // rest of the prefetch and consumed an iteration later).
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   auto load_ptr = [&](int cbx, int f0x) {
-    long base = (long)cbx * g.F;
+    long base = (long)cbx * g.F + vzero;
     pn0 = g.t_ptr[base + f0x];
     pn1 = g.t_ptr[base + min(f0x + FT, g.F)];
   };
@@ -200,14 +218,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
     for (int i = 0; i < EPF; i++) {
       const int e = ep0 + tid + 256 * i;
-      if (UNPRED) {
-        const int ec = max(min(e, ep1 - 1), 0);   // clamped (the entry arrays hold at least one element): no predicated load
-        ekey[i] = g.t_key[ec];                      // validity is recomputed from (ep0, ep1) where the entry is used:
-        evl[i] = g.t_val ? g.t_val[ec] : 1.f;     // no use of the loaded value here (it would wait for the load)
-      } else {
-        ekey[i] = (e < ep1) ? g.t_key[e] : -1;
-        evl[i] = (e < ep1 && g.t_val) ? g.t_val[e] : 1.f;
-      }
+      const int ec = max(min(e, ep1 - 1), 0);     // clamped (the entry arrays hold at least one element): no predicated load
+      ekey[i] = g.t_key[ec];                      // validity is recomputed from (ep0, ep1) where the entry is used:
+      evl[i] = e_val[ec];                         // no use of the loaded values here (it would wait for the loads)
     }
   };
   const int ntl = min(NPT, (g.F - f_chunk0 + FT - 1) / FT);     // valid feature tiles of this chunk (>= 1)
@@ -223,6 +236,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     }
   }
 
+#ifdef DEC_PROF
+  const bool prof_on = (tid == 0) && (blockIdx.x == gridDim.x / 2) && (blockIdx.y == 0) && g.prof;
+  int prof_it = 0;
+#endif
   for (int cb = cb_beg; cb < cb_end; cb++) {
     const int c0 = cb * CB;
     f32x16 accH;
@@ -242,36 +259,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     for (int t = 0; t < NPT; t++) {
       const int f0 = f_chunk0 + t * FT;
       if (t < ntl) {                              // uniform
+      PROF_MARK(0);
       __syncthreads();                            // previous iteration's readers are done
+      PROF_MARK(1);
       if (t == 0) {
         // ---- h block (both layouts) and the per-cell inputs, from the prefetch registers ---------------
-        put_rows(hreg, std::integral_constant<bool, UNPRED>{}, vec_h, c0 + sp < g.B, hA, hT);
+        put_rows(hreg, hA, hT);
         if (tid < CB) {
-          int c = c0 + tid;
-          bool ok = c < g.B;
+          const bool ok = c0 + tid < g.B;
           if (IS_BER) {
-            float l = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 0.f;
-            rowv[tid] = g.lrow ? sigm_<FAST>(l) : 1.f;
+            rowv[tid] = g.lrow ? sigm_<FAST>(ok ? row_n[0] : 0.f) : 1.f;
           } else {
-            rowv[tid] = (g.lrow && ok) ? g.lrow[g.lrow_n == 1 ? 0 : c] : 1.f;          // L
-            rowv[CB + tid] = (g.rowlse && ok) ? g.rowlse[c] : 0.f;                     // lse
-            rowv[2 * CB + tid] = (g.rowT && ok) ? g.rowT[c] : 0.f;                     // T
+            rowv[tid] = (g.lrow && ok) ? row_n[0] : 1.f;                   // L
+            rowv[CB + tid] = (g.rowlse && ok) ? row_n[1] : 0.f;            // lse
+            rowv[2 * CB + tid] = (g.rowT && ok) ? row_n[2] : 0.f;          // T
           }
         }
       }
       // ---- W tile (both layouts) from the prefetch registers, clear label tile ---------------------
-      put_rows(wreg, std::false_type{}, vec_w, true, WB, WT);
+      put_rows(wreg, WB, WT);
+      const float bias_c = bias_n, fs_c = fs_n, th_c = th_n;      // this tile's scalars, before the next prefetch
       if (NEED_LABELS) {
         float4 z4 = {0.f, 0.f, 0.f, 0.f};
         for (int idx = tid; idx < CB * FT / 4; idx += 256) ((float4*)ytile)[idx] = z4;
         if (tid == 0) tflag = 0;
+        PROF_MARK(2);
         __syncthreads();
+        PROF_MARK(3);
         bool odd = false;
 #pragma unroll
         for (int i = 0; i < EPF; i++)
-          if (UNPRED ? (ep0 + tid + 256 * i < ep1) : (ekey[i] >= 0)) {
-            ytile[(ekey[i] & 63) * FT + ((ekey[i] >> 6) - f0)] = evl[i];
-            odd |= !(evl[i] == 1.f);
+          if (ep0 + tid + 256 * i < ep1) {
+            const float v = g.t_val ? evl[i] : 1.f;
+            ytile[(ekey[i] & 63) * FT + ((ekey[i] >> 6) - f0)] = v;
+            odd |= !(v == 1.f);
           }
         for (int e = ep0 + tid + 256 * EPF; e < ep1; e += 256) {
           int key = g.t_key[e];
@@ -281,14 +302,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         }
         if (IS_BER && odd) tflag = 1;
       }
+      PROF_MARK(11);
       // ---- issue the loads of the NEXT iteration; they complete under the MFMA + epilogue below -------
       {
         const bool more_t = (t + 1 < ntl);
         const int cbn = more_t ? cb : cb + 1;
         const int f0n = more_t ? f0 + FT : f_chunk0;
         if (cbn < cb_end) {
-          load_w(f0n);
-          if (!more_t) load_h(cbn * CB);
+          // the entry loads come first: their addresses need the range words fetched one iteration ago, and a wait
+          // for those placed after this iteration's operand loads would wait for these too (loads return in order)
           if (NEED_LABELS) {
             load_entries();                       // uses the range fetched one iteration ago
             // range of the iteration after the next one
@@ -297,9 +319,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             const int f02 = more_t2 ? f0n + FT : f_chunk0;
             if (cb2 < cb_end) load_ptr(cb2, f02);
           }
+          load_w(f0n);
+          if (!more_t) load_h(cbn * CB);
         }
       }
+      PROF_MARK(4);
       __syncthreads();
+      PROF_MARK(5);
       // ---- Z = h W^T -----------------------------------------------------------------------------
       f32x16 acc;
 #pragma unroll
@@ -319,20 +345,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             if (sa + sb < NS) acc = mfma32(a[sa], b[sb], acc);
       }
       // ---- epilogue ------------------------------------------------------------------------------
+      PROF_MARK(6);
       const int fl = tj * 32 + r;                 // feature inside tile
       const int f = f0 + fl;
       const bool f_ok = f < g.F;
-      const float bcol = f_ok ? g.bias[f] : 0.f;
+      const float bcol = f_ok ? bias_c : 0.f;
       float fcol = 1.f;
-      if (g.fs && f_ok) fcol = sigm_<FAST>(g.fs[f]);
+      if (g.fs && f_ok) fcol = sigm_<FAST>(fs_c);
       float thcol = 0.f;
-      if (!IS_BER && g.theta_param && f_ok) thcol = exp_<FAST>(g.theta_param[f]);
+      if (!IS_BER && g.theta_param && f_ok) thcol = exp_<FAST>(th_c);
       float dzv[16];
       float lsum = 0.f;     // fp32 partial of this tile, folded into the fp64 accumulator once per tile
       // Bernoulli, interior tile with 0/1 labels only: no bounds / NaN / soft-label handling (same algebra)
       const bool ber_fast = IS_BER && (f0 + FT <= g.F) && (c0 + CB <= g.B) && (tflag == 0);
       if (ber_fast) {
         float su = 0.f, sd = 0.f;
+#if defined(DEC_EXP) && DEC_EXP == 2
+#pragma unroll
+        for (int e = 0; e < 16; e++) { dzv[e] = acc[e] * inv_n; lsum += acc[e]; }
+#elif defined(DEC_EXP) && DEC_EXP == 1
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int cl = ti * 32 + acc_row(e, lane);
+          float ex = (acc[e] + bcol) * (acc[e] + bcol);
+          float px = (1.f + ex) * 0.5f;
+          float sr = rowv[cl];
+          float q = px * sr * fcol;
+          float omq = 1.f - q;
+          float yv = ytile[cl * FT + fl];
+          float arg = (yv == 0.f) ? omq : q;
+          lsum -= fmaxf(arg + 1.f, -100.f);
+          if (TRAIN) {
+            float u = (q - yv) * (fmaxf(q * omq, 1e-12f) * 0.25f) * inv_n * q;     // dL/dq * q
+            float d = u * (1.f - px);
+            dzv[e] = d;
+            racc0[e] += u * (1.f - sr);
+            su += u;
+            sd += d;
+          }
+        }
+#else
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int cl = ti * 32 + acc_row(e, lane);
@@ -352,6 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             sd += d;
           }
         }
+#endif
         if (TRAIN) {
           dfs_acc[0] += su * (1.f - fcol);
           db_acc[0] += sd;
@@ -479,6 +532,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         }
       }
       loss_acc += (double)lsum;
+      PROF_MARK(7);
       if (TRAIN) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
@@ -500,7 +554,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             *(bf16x4*)&dzT[(s2 * FT + fl) * LDZ + cl0] = o;
           }
         }
+        PROF_MARK(8);
         __syncthreads();
+        PROF_MARK(9);
         // ---- dW tile += dZ^T h ; dh block += dZ W -----------------------------------------------
         const int mi = wave & 1, nj = wave >> 1;
         if (nj < NTK) {
@@ -541,6 +597,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         accW[NPT - 1] = w0;
         db_acc[NPT - 1] = b0; dfs_acc[NPT - 1] = s0; dth_acc[NPT - 1] = h0;
       }
+      PROF_MARK(10);
+#ifdef DEC_PROF
+      prof_it++;
+#endif
     }  // feature tiles
 
     // ---- per-cell results of this block ---------------------------------------------------------
@@ -549,11 +609,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       if (nj < NTK) {
         int k = nj * 32 + r;
         if (k < g.K) {
+          // slab rows are padded to whole cell blocks: one base address, compile-time row offsets, no predicates
+          float* dst = g.dh_slab + ((long)blockIdx.x * (ncb * CB) + c0 + mi * 32 + 4 * hq) * KP + k;
 #pragma unroll
-          for (int e = 0; e < 16; e++) {
-            int c = c0 + mi * 32 + acc_row(e, lane);
-            if (c < g.B) g.dh_slab[((long)blockIdx.x * g.B + c) * KP + k] = accH[e];
-          }
+          for (int e = 0; e < 16; e++) dst[((e & 3) + 8 * (e >> 2)) * KP] = accH[e];
         }
       }
     }
@@ -667,17 +726,26 @@ static size_t dec_smem() {
   return bf * sizeof(__bf16) + sizeof(float) * (CB * FT + 3 * CB + 4 * CB);
 }
 
-template <int NS, int KP, int MODE>
-static int dec_launch(const DecArgs& g, int grid, hipStream_t stream) {
+template <int NS, int KP, int MODE, bool VEC>
+static int dec_launch_v(const DecArgs& g, int grid, hipStream_t stream) {
   const int ncb_ = (g.B + CB - 1) / CB;
   const int ncg_ = (ncb_ + g.cpg - 1) / g.cpg;
   static uint64_t attr_done = 0;
   size_t smem = dec_smem<NS, KP>();
-  int rc_ = scp_set_smem((const void*)dec_kernel<NS, KP, DEC_NPT, MODE>, smem, &attr_done);
+  int rc_ = scp_set_smem((const void*)dec_kernel<NS, KP, DEC_NPT, MODE, VEC>, smem, &attr_done);
   if (rc_) return rc_;
-  hipLaunchKernelGGL((dec_kernel<NS, KP, DEC_NPT, MODE>), dim3(grid, ncg_), dim3(256), smem, stream, g);
+  hipLaunchKernelGGL((dec_kernel<NS, KP, DEC_NPT, MODE, VEC>), dim3(grid, ncg_), dim3(256), smem, stream, g);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
+}
+
+template <int NS, int KP, int MODE>
+static int dec_launch(const DecArgs& g, int grid, hipStream_t stream) {
+  // buffer-load path of the operand blocks: 16-byte rows and 32-bit byte offsets
+  const bool vec = ((g.K & 3) == 0) && ((g.ldw & 3) == 0) && ((g.ldh & 3) == 0) && ((((uintptr_t)g.W) & 15) == 0) &&
+                   ((((uintptr_t)g.h) & 15) == 0) && ((long)(g.F + 2 * FT) * g.ldw * 4 < (1L << 30)) &&
+                   ((long)(g.B + 2 * CB) * g.ldh * 4 < (1L << 30));
+  return vec ? dec_launch_v<NS, KP, MODE, true>(g, grid, stream) : dec_launch_v<NS, KP, MODE, false>(g, grid, stream);
 }
 
 // one translation unit per (NS, family) keeps the build parallel
