@@ -227,7 +227,7 @@ def main():
         # the two predictors share nothing but the minibatch: one stream each, both after the tile-list build
         cur = torch.cuda.current_stream()
         for t in (t_rna, t_atac):
-            for x in (t.ptr, t.key, t.val, t.lib, t.nnan, t.rows):
+            for x in (t.ptr, t.key, t.val, t.pk, t.lib, t.nnan, t.rows):
                 if x is not None:
                     for st in side:
                         x.record_stream(st)

@@ -29,6 +29,8 @@ long scp_tiles_ptr_len(int B, int F);   /* int32 elements needed for `ptr` */
 long scp_tiles_ws_len(int B, int F);    /* int32 elements needed for `ws`  */
 int scp_tiles_build(const int64_t* indptr, const int32_t* indices, const float* values /* null: implicit 1 */,
                     const int64_t* rows, int B, int F, int32_t* ptr, int32_t* key, float* val /* nullable */,
+                    uint32_t* pk /* nullable; written when values and val are given: the packed entries
+                                    (bf16 bits of the value) << 16 | (key & 0xffff) the bf16 first-layer kernels read */,
                     float* lib /* [B] row sums, nullable */, int32_t* nnan /* [1], nullable */, int32_t* ws,
                     void* stream);
 /* tile list -> dense [B][ld] fp32 labels (zeros elsewhere) for the likelihoods evaluated on materialised tensors
@@ -37,8 +39,8 @@ int scp_tiles_to_dense(int B, int F, const int32_t* t_ptr, const int32_t* t_key,
                        void* stream);
 /* Optional input pre-transform on a minibatch tile list, in place (no counterpart in the reference, which feeds raw
  * counts: model.py:492-510; opt-in, default off): mode 1: v <- log1p(v); mode 2: v <- log1p(v * scale / lib[cell]). */
-int scp_tiles_transform(int B, int F, const int32_t* ptr, const int32_t* key, float* val, const float* lib, int mode,
-                        float scale, void* stream);
+int scp_tiles_transform(int B, int F, const int32_t* ptr, const int32_t* key, float* val, uint32_t* pk /* nullable, kept in step */,
+                        const float* lib, int mode, float scale, void* stream);
 
 /* ---- first encoder layer on sparse counts: nn.Linear(F_in, H) of FCNN (utils.py:57) applied to
  *      the dense x in Input_Module (model.py:128-130, 136-140), forward and weight gradient ---- */
@@ -56,21 +58,22 @@ int scp_spmm_dw(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t
 int scp_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
 int scp_transpose_bf16(const float* src, int rows, int cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
 int scp_spmm_fwd_bf16_min_split(int F);   /* smallest nsplit scp_spmm_fwd_bf16 accepts for F features */
+/* t_pk: the packed entries of scp_tiles_build; required when t_val is given (the kernels read them instead of key / val) */
 int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
-                      const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream);
+                      const uint32_t* t_pk, const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream);
 int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
-                     const void* dYT, long ldt, float* dW, long ldw, void* stream);
+                     const uint32_t* t_pk, const void* dYT, long ldt, float* dW, long ldw, void* stream);
 /* The same weight gradient written as bf16 [N][ldw] (data-parallel training in precision mode 'bf16': the kernel writes
  * straight into the exchange buffer that the all-reduce sums and scp_adamw_multi then reads, g_bf16 = 1) */
 int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
-                         const void* dYT, long ldt, void* dW_bf16, long ldw, void* stream);
+                         const uint32_t* t_pk, const void* dYT, long ldt, void* dW_bf16, long ldw, void* stream);
 /* The same weight gradient with the AdamW step of that weight (model.py:698-701, torch.optim.AdamW semantics as in
  * scp_adamw_multi) applied in the kernel's epilogue: W [N][ldw] fp32 master weights, exp_avg / exp_avg_sq (same
  * layout) and the bf16 shadow are updated in place and the gradient never reaches HBM.  For single-process training
  * (no gradient exchange between backward and the optimiser step).  Needs F % 4 == 0, ldw % 4 == 0, ld_bf16 % 4 == 0
  * and 16-byte aligned W / moments (SCP_ERR_SHAPE otherwise: use scp_spmm_dw_bf16 + scp_adamw_multi). */
 int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
-                           const void* dYT, long ldt, float* W, long ldw, float* exp_avg, float* exp_avg_sq,
+                           const uint32_t* t_pk, const void* dYT, long ldt, float* W, long ldw, float* exp_avg, float* exp_avg_sq,
                            void* W_bf16, long ld_bf16, float lr, float weight_decay, float beta1, float beta2, float eps,
                            float bias_corr1, float bias_corr2, float grad_scale,
                            const float* bc_dev /* nullable: device {bias_corr1, bias_corr2} used instead of the values */,

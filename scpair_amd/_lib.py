@@ -47,18 +47,18 @@ _SIGS = {
     "scp_tiles_ptr_len": (L, [I, I]),
     "scp_tiles_ws_len": (L, [I, I]),
     "scp_tiles_to_dense": (I, [I, I, P, P, P, P, L, P]),
-    "scp_tiles_transform": (I, [I, I, P, P, P, P, I, F, P]),
-    "scp_tiles_build": (I, [P, P, P, P, I, I, P, P, P, P, P, P, P]),
+    "scp_tiles_transform": (I, [I, I, P, P, P, P, P, I, F, P]),
+    "scp_tiles_build": (I, [P, P, P, P, I, I, P, P, P, P, P, P, P, P]),
     "scp_gemm_split_count": (I, [I, I]),
     "scp_spmm_fwd": (I, [I, I, I, P, P, P, P, L, P, L, P, I, I, P]),
     "scp_spmm_dw": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
     "scp_cast_bf16": (I, [P, L, L, L, P, L, P]),
     "scp_transpose_bf16": (I, [P, I, I, L, P, L, P]),
     "scp_spmm_fwd_bf16_min_split": (I, [I]),
-    "scp_spmm_fwd_bf16": (I, [I, I, I, P, P, P, P, L, P, L, I, P]),
-    "scp_spmm_dw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
-    "scp_spmm_dw_bf16_g16": (I, [I, I, I, P, P, P, P, L, P, L, P]),
-    "scp_spmm_dw_adamw_bf16": (I, [I, I, I, P, P, P, P, L, P, L, P, P, P, L, F, F, F, F, F, F, F, F, P, P]),
+    "scp_spmm_fwd_bf16": (I, [I, I, I, P, P, P, P, P, L, P, L, I, P]),
+    "scp_spmm_dw_bf16": (I, [I, I, I, P, P, P, P, P, L, P, L, P]),
+    "scp_spmm_dw_bf16_g16": (I, [I, I, I, P, P, P, P, P, L, P, L, P]),
+    "scp_spmm_dw_adamw_bf16": (I, [I, I, I, P, P, P, P, P, L, P, L, P, P, P, L, F, F, F, F, F, F, F, F, P, P]),
     "scp_gemm_nt": (I, [I, I, I, P, L, L, P, L, L, P, L, P, I, I, I, P]),
     "scp_gemm_lib_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P]),
     "scp_slab_reduce": (I, [P, L, I, I, I, L, P, P, L, P]),

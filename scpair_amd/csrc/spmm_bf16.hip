@@ -22,6 +22,9 @@
 struct SpArgs {
   int ncells, N, F;          // cells, hidden width, features
   const int32_t* ptr; const int32_t* key; const float* val;
+  const uint32_t* pk;        // value-carrying data: packed entries (bf16 bits of the value) << 16 | (key & 0xffff), written by
+                             // scp_tiles_build next to key / val: one load and one register per entry instead of two, and the
+                             // value goes to LDS as it is (the unpacked form rounded it to bf16 at the same place)
   int ncb;
   const __bf16* D; long ldd; // dense bf16 operand: forward Wbf[N][ldd] ; wgrad dYT[N][ldd]
   float* C; long ldc;        // forward: slabs [nsplit][ncells][ldc] ; wgrad: dW[N][ldc]
@@ -59,7 +62,7 @@ __device__ __forceinline__ uint32_t gload_b32_sync(const void* p) {
 // ------------------------------------------------------------------------------------------------------
 template <bool HASVAL>
 __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
-  constexpr int EPT = HASVAL ? 4 : 2;             // sparse entries held per thread and stage
+  constexpr int EPT = HASVAL ? 6 : 2;             // sparse entries held per thread and stage (C2 RNA: up to 673 of 768 slots)
   constexpr int ASZ = 256 * LDK, BSZ = 128 * LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* As = (__bf16*)smem_raw;        // [3][256][LDK]
@@ -93,12 +96,12 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
       for (int e = 0; e < 16; e++) acc[i][jj][e] = 0.f;
 
   u32x4 breg[3][2];
-  uint32_t ekey[3][EPT], eval_[3][HASVAL ? EPT : 1];
+  uint32_t ekey[3][EPT];                          // key words, or packed (value, key) words when HASVAL
   int p0[3], p1[3];
   int skey[3][EPT];                               // LDS offsets this thread scattered for step j (slot j%3), -1 = none
   const int brow = tid >> 3, bkc = tid & 7;       // B tile chunk of this thread (and +64 rows for the second one)
 
-  auto prefetch = [&](u32x4 (&br)[2], uint32_t (&ek)[EPT], uint32_t (&ev)[HASVAL ? EPT : 1], int& q0, int& q1,
+  auto prefetch = [&](u32x4 (&br)[2], uint32_t (&ek)[EPT], int& q0, int& q1,
                       int step) {
     const int k0 = kbeg + 64 * step;
 #pragma unroll
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
       int e = min(q0 + tl + 128 * i, elast);
-      ek[i] = (uint32_t)g.key[e];
-      if constexpr (HASVAL) ev[i] = __float_as_uint(g.val[e]);
+      if constexpr (HASVAL) ek[i] = g.pk[e];
+      else ek[i] = (uint32_t)g.key[e];
     }
   };
 
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
     }
   };
   // registers of one stage -> LDS operands of `step`
-  auto stage_out = [&](const u32x4 (&br)[2], const uint32_t (&ek)[EPT], const uint32_t (&ev)[HASVAL ? EPT : 1], int q0,
+  auto stage_out = [&](const u32x4 (&br)[2], const uint32_t (&ek)[EPT], int q0,
                        int q1, int step, int (&sk)[EPT]) {
     const int k0 = kbeg + 64 * step;
     __bf16* Ad = As + (step % 3) * ASZ;
@@ -148,21 +151,28 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
     for (int i = 0; i < EPT; i++) {
       sk[i] = -1;
       if (q0 + tl + 128 * i < q1) {
-        int key = (int)ek[i];
-        float v = 1.f;
-        if constexpr (HASVAL) v = __uint_as_float(ev[i]);
-        int off = (cbl * 64 + (key & 63)) * LDK + ((key >> 6) - k0);
-        Ad[off] = (__bf16)v;
-        sk[i] = off;
+        const uint32_t w = ek[i];
+        if constexpr (HASVAL) {                   // k0 is a multiple of 64: the low key bits are the position in the tile
+          int off = (cbl * 64 + (w & 63)) * LDK + ((w >> 6) & 63);
+          ((uint16_t*)Ad)[off] = (uint16_t)(w >> 16);
+          sk[i] = off;
+        } else {
+          int off = (cbl * 64 + (w & 63)) * LDK + (((int)w >> 6) - k0);
+          Ad[off] = (__bf16)1.f;
+          sk[i] = off;
+        }
       }
     }
     if (q0 + 128 * EPT < q1) {                    // overflow of a dense (cell block, K-step): rare, uniform per wave
       if (tl == 0) ovf[step % 3] = step + 1;
       for (int e = q0 + tl + 128 * EPT; e < q1; e += 128) {
-        int key = (int)gload_b32_sync(g.key + e);
-        float v = 1.f;
-        if constexpr (HASVAL) v = __uint_as_float(gload_b32_sync(g.val + e));
-        Ad[(cbl * 64 + (key & 63)) * LDK + ((key >> 6) - k0)] = (__bf16)v;
+        if constexpr (HASVAL) {
+          const uint32_t w = gload_b32_sync(g.pk + e);
+          ((uint16_t*)Ad)[(cbl * 64 + (w & 63)) * LDK + ((w >> 6) & 63)] = (uint16_t)(w >> 16);
+        } else {
+          int key = (int)gload_b32_sync(g.key + e);
+          Ad[(cbl * 64 + (key & 63)) * LDK + ((key >> 6) - k0)] = (__bf16)1.f;
+        }
       }
     }
   };
@@ -193,9 +203,9 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 3; s++)
-      if (s < nstep) prefetch(breg[s], ekey[s], eval_[s], p0[s], p1[s], s);
-    stage_out(breg[0], ekey[0], eval_[0], p0[0], p1[0], 0, skey[0]);
-    if (3 < nstep) prefetch(breg[0], ekey[0], eval_[0], p0[0], p1[0], 3);
+      if (s < nstep) prefetch(breg[s], ekey[s], p0[s], p1[s], s);
+    stage_out(breg[0], ekey[0], p0[0], p1[0], 0, skey[0]);
+    if (3 < nstep) prefetch(breg[0], ekey[0], p0[0], p1[0], 3);
     __syncthreads();
   }
   // One K-step.  FULL = every neighbour the step touches exists (steps i-1 .. i+4), so the body is straight-line:
@@ -222,11 +232,11 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
         for (int jj = 0; jj < 2; jj++) acc[q][jj] = mfma32(af[kk][q], bfr[kk][jj], acc[q][jj]);
     };
     // ---- operands of step i+1 (stage s1) -----------------------------------------------------------------------
-    if (FULL || i + 1 < nstep) stage_out(breg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 1, skey[s1]);
+    if (FULL || i + 1 < nstep) stage_out(breg[s1], ekey[s1], p0[s1], p1[s1], i + 1, skey[s1]);
     mfma_group(0);
     mfma_group(1);
     // ---- loads of step i+4 into the stage just drained; restore the buffer of step i-1 for step i+2 -----------
-    if (FULL || i + 4 < nstep) prefetch(breg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 4);
+    if (FULL || i + 4 < nstep) prefetch(breg[s1], ekey[s1], p0[s1], p1[s1], i + 4);
     mfma_group(2);
     if (FULL || (i >= 1 && i + 2 < nstep)) unscatter(i - 1, skey[s2]);
     mfma_group(3);
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
 // ------------------------------------------------------------------------------------------------------
 template <bool HASVAL, bool ADAM, bool OUT16 = false, int EPB = 16>
 __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
-  constexpr int EPT = HASVAL ? 4 : 2;             // sparse entries held per thread and stage
+  constexpr int EPT = HASVAL ? 5 : 2;             // sparse entries held per thread and stage
   constexpr int ASZ = 128 * LDK, BSZ = 256 * LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* Bs = (__bf16*)smem_raw;        // [3][256][LDK]   X tile    [feature][cell]
@@ -314,12 +324,12 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
       for (int e = 0; e < 16; e++) acc[i][jj][e] = 0.f;
 
   u32x4 areg[3][2];
-  uint32_t ekey[3][EPT], eval_[3][HASVAL ? EPT : 1];
+  uint32_t ekey[3][EPT];                          // key words, or packed (value, key) words when HASVAL
   int p0[3], p1[3];
   int skey[3][EPT];                               // LDS offsets this thread scattered for step j (slot j%3), -1 = none
   const int arow = tid >> 3, akc = tid & 7;       // dYT tile chunk of this thread (and +64 rows for the second one)
 
-  auto prefetch = [&](u32x4 (&ar)[2], uint32_t (&ek)[EPT], uint32_t (&ev)[HASVAL ? EPT : 1], int& q0, int& q1,
+  auto prefetch = [&](u32x4 (&ar)[2], uint32_t (&ek)[EPT], int& q0, int& q1,
                       int step) {
     const int k0 = step * 64;
 #pragma unroll
@@ -334,12 +344,12 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
       int e = min(q0 + tid + 512 * i, elast);
-      ek[i] = (uint32_t)g.key[e];
-      if constexpr (HASVAL) ev[i] = __float_as_uint(g.val[e]);
+      if constexpr (HASVAL) ek[i] = g.pk[e];
+      else ek[i] = (uint32_t)g.key[e];
     }
   };
   // registers of one stage -> LDS operands of `step`
-  auto stage_out = [&](const u32x4 (&ar)[2], const uint32_t (&ek)[EPT], const uint32_t (&ev)[HASVAL ? EPT : 1], int q0,
+  auto stage_out = [&](const u32x4 (&ar)[2], const uint32_t (&ek)[EPT], int q0,
                        int q1, int step, int (&sk)[EPT]) {
     const int k0 = step * 64;
     __bf16* Ad = As + (step & 1) * ASZ;
@@ -355,21 +365,28 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
     for (int i = 0; i < EPT; i++) {
       sk[i] = -1;
       if (q0 + tid + 512 * i < q1) {
-        int key = (int)ek[i];
-        float v = 1.f;
-        if constexpr (HASVAL) v = __uint_as_float(ev[i]);
-        int off = ((key >> 6) - n0) * LDK + (key & 63);
-        Bd[off] = (__bf16)v;
-        sk[i] = off;
+        const uint32_t w = ek[i];
+        if constexpr (HASVAL) {                   // n0 is a multiple of 256: the low key bits are the position in the tile
+          int off = ((w >> 6) & 255) * LDK + (w & 63);
+          ((uint16_t*)Bd)[off] = (uint16_t)(w >> 16);
+          sk[i] = off;
+        } else {
+          int off = (((int)w >> 6) - n0) * LDK + (w & 63);
+          Bd[off] = (__bf16)1.f;
+          sk[i] = off;
+        }
       }
     }
     if (q0 + 512 * EPT < q1) {                    // overflow of a dense (cell block, feature tile): rare, uniform
       if (tid == 0) ovf[step % 3] = step + 1;
       for (int e = q0 + tid + 512 * EPT; e < q1; e += 512) {
-        int key = (int)gload_b32_sync(g.key + e);
-        float v = 1.f;
-        if constexpr (HASVAL) v = __uint_as_float(gload_b32_sync(g.val + e));
-        Bd[((key >> 6) - n0) * LDK + (key & 63)] = (__bf16)v;
+        if constexpr (HASVAL) {
+          const uint32_t w = gload_b32_sync(g.pk + e);
+          ((uint16_t*)Bd)[((w >> 6) & 255) * LDK + (w & 63)] = (uint16_t)(w >> 16);
+        } else {
+          int key = (int)gload_b32_sync(g.key + e);
+          Bd[((key >> 6) - n0) * LDK + (key & 63)] = (__bf16)1.f;
+        }
       }
     }
   };
@@ -404,9 +421,9 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 3; s++)
-    if (s < nstep) prefetch(areg[s], ekey[s], eval_[s], p0[s], p1[s], s);
-  stage_out(areg[0], ekey[0], eval_[0], p0[0], p1[0], 0, skey[0]);
-  if (3 < nstep) prefetch(areg[0], ekey[0], eval_[0], p0[0], p1[0], 3);
+    if (s < nstep) prefetch(areg[s], ekey[s], p0[s], p1[s], s);
+  stage_out(areg[0], ekey[0], p0[0], p1[0], 0, skey[0]);
+  if (3 < nstep) prefetch(areg[0], ekey[0], p0[0], p1[0], 3);
   __syncthreads();
 
   // One K-step; FULL = steps i-1 .. i+4 all exist (straight-line body, see the forward kernel)
@@ -430,10 +447,10 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) acc[q][jj] = mfma32(af[kk][q], bfr[kk][jj], acc[q][jj]);
     };
-    if (FULL || i + 1 < nstep) stage_out(areg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 1, skey[s1]);
+    if (FULL || i + 1 < nstep) stage_out(areg[s1], ekey[s1], p0[s1], p1[s1], i + 1, skey[s1]);
     mfma_group(0);
     mfma_group(1);
-    if (FULL || i + 4 < nstep) prefetch(areg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 4);
+    if (FULL || i + 4 < nstep) prefetch(areg[s1], ekey[s1], p0[s1], p1[s1], i + 4);
     mfma_group(2);
     if (FULL || (i >= 1 && i + 2 < nstep)) unscatter(i - 1, skey[s2]);
     mfma_group(3);
@@ -544,7 +561,7 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
 // ------------------------------------------------------------------------------------------------------
 template <bool HASVAL, bool ADAM, bool OUT16 = false, int EPB = 16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void spmm_dw128_bf16_kernel(SpArgs g) {
-  constexpr int EPT = HASVAL ? 4 : 2;             // sparse entries held per thread and stage
+  constexpr int EPT = HASVAL ? 5 : 2;             // sparse entries held per thread and stage
   constexpr int ASZ = 128 * LDK, BSZ = 128 * LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* Bs = (__bf16*)smem_raw;        // [2][128][LDK]   X tile    [feature][cell]
@@ -572,12 +589,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       for (int e = 0; e < 16; e++) acc[i][jj][e] = 0.f;
 
   u32x4 areg[3][4];
-  uint32_t ekey[3][EPT], eval_[3][HASVAL ? EPT : 1];
+  uint32_t ekey[3][EPT];                          // key words, or packed (value, key) words when HASVAL
   int p0[3], p1[3];
   int skey[3][EPT];                               // LDS offsets this thread scattered for step j (slot j%3), -1 = none
   const int arow = tid >> 3, akc = tid & 7;       // dYT tile chunks of this thread: rows arow, +32, +64, +96
 
-  auto prefetch = [&](u32x4 (&ar)[4], uint32_t (&ek)[EPT], uint32_t (&ev)[HASVAL ? EPT : 1], int& q0, int& q1,
+  auto prefetch = [&](u32x4 (&ar)[4], uint32_t (&ek)[EPT], int& q0, int& q1,
                       int step) {
     const int k0 = step * 64;
 #pragma unroll
@@ -592,12 +609,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
       int e = min(q0 + tid + 256 * i, elast);
-      ek[i] = (uint32_t)g.key[e];
-      if constexpr (HASVAL) ev[i] = __float_as_uint(g.val[e]);
+      if constexpr (HASVAL) ek[i] = g.pk[e];
+      else ek[i] = (uint32_t)g.key[e];
     }
   };
   // registers of one stage -> LDS operands of `step`
-  auto stage_out = [&](const u32x4 (&ar)[4], const uint32_t (&ek)[EPT], const uint32_t (&ev)[HASVAL ? EPT : 1], int q0,
+  auto stage_out = [&](const u32x4 (&ar)[4], const uint32_t (&ek)[EPT], int q0,
                        int q1, int step, int (&sk)[EPT]) {
     const int k0 = step * 64;
     __bf16* Ad = As + (step & 1) * ASZ;
@@ -613,21 +630,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     for (int i = 0; i < EPT; i++) {
       sk[i] = -1;
       if (q0 + tid + 256 * i < q1) {
-        int key = (int)ek[i];
-        float v = 1.f;
-        if constexpr (HASVAL) v = __uint_as_float(ev[i]);
-        int off = ((key >> 6) - n0) * LDK + (key & 63);
-        Bd[off] = (__bf16)v;
-        sk[i] = off;
+        const uint32_t w = ek[i];
+        if constexpr (HASVAL) {                   // n0 is a multiple of 128: the low key bits are the position in the tile
+          int off = ((w >> 6) & 127) * LDK + (w & 63);
+          ((uint16_t*)Bd)[off] = (uint16_t)(w >> 16);
+          sk[i] = off;
+        } else {
+          int off = (((int)w >> 6) - n0) * LDK + (w & 63);
+          Bd[off] = (__bf16)1.f;
+          sk[i] = off;
+        }
       }
     }
     if (q0 + 256 * EPT < q1) {                    // overflow of a dense (cell block, feature tile): rare, uniform
       if (tid == 0) ovf[step % 3] = step + 1;
       for (int e = q0 + tid + 256 * EPT; e < q1; e += 256) {
-        int key = (int)gload_b32_sync(g.key + e);
-        float v = 1.f;
-        if constexpr (HASVAL) v = __uint_as_float(gload_b32_sync(g.val + e));
-        Bd[((key >> 6) - n0) * LDK + (key & 63)] = (__bf16)v;
+        if constexpr (HASVAL) {
+          const uint32_t w = gload_b32_sync(g.pk + e);
+          ((uint16_t*)Bd)[((w >> 6) & 127) * LDK + (w & 63)] = (uint16_t)(w >> 16);
+        } else {
+          int key = (int)gload_b32_sync(g.key + e);
+          Bd[((key >> 6) - n0) * LDK + (key & 63)] = (__bf16)1.f;
+        }
       }
     }
   };
@@ -661,9 +685,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 3; s++)
-    if (s < nstep) prefetch(areg[s], ekey[s], eval_[s], p0[s], p1[s], s);
-  stage_out(areg[0], ekey[0], eval_[0], p0[0], p1[0], 0, skey[0]);
-  if (3 < nstep) prefetch(areg[0], ekey[0], eval_[0], p0[0], p1[0], 3);
+    if (s < nstep) prefetch(areg[s], ekey[s], p0[s], p1[s], s);
+  stage_out(areg[0], ekey[0], p0[0], p1[0], 0, skey[0]);
+  if (3 < nstep) prefetch(areg[0], ekey[0], p0[0], p1[0], 3);
   __syncthreads();
 
   // One K-step; FULL = steps i-1 .. i+4 all exist (straight-line body, see the forward kernel)
@@ -690,10 +714,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) acc[q][jj] = mfma32(af[kk][q], bfr[kk][jj], acc[q][jj]);
     };
-    if (FULL || i + 1 < nstep) stage_out(areg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 1, skey[s1]);
+    if (FULL || i + 1 < nstep) stage_out(areg[s1], ekey[s1], p0[s1], p1[s1], i + 1, skey[s1]);
     mfma_group(0);
     mfma_group(1);
-    if (FULL || i + 4 < nstep) prefetch(areg[s1], ekey[s1], eval_[s1], p0[s1], p1[s1], i + 4);
+    if (FULL || i + 4 < nstep) prefetch(areg[s1], ekey[s1], p0[s1], p1[s1], i + 4);
     mfma_group(2);
     mfma_group(3);
     __syncthreads();
@@ -842,10 +866,10 @@ extern "C" int scp_transpose_bf16(const float* src, int rows, int cols, long ld_
 
 static int set_smem(const void* fn, size_t smem, uint64_t* done) { return scp_set_smem(fn, smem, done); }
 
-// Feature-tile width of the fused weight-gradient + AdamW launch: 128 (two workgroups per CU) for implicit-ones
-// data, 256 (one workgroup per CU) for data with values -- measured at C2: 519 against 555 us for the 900 x 100 k
-// ATAC weights, 175 against 160 us for 900 x 20 k RNA weights (four value-carrying entries per thread and step
-// spill in the narrow variant).  SCPAIR_DW_TILE = 128 / 256 overrides.
+// Feature-tile width of the fused weight-gradient + AdamW launch: 128 (two workgroups per CU: the AdamW epilogue of one
+// overlaps the K loop of the other) -- measured at C2: 519 against 555 us for the 900 x 100 k ATAC weights; for the
+// 900 x 20 k RNA weights 150 against 159 us since value-carrying entries travel as one packed word (with separate key
+// and value registers the narrow variant spilled and lost, 175 against 160 us).  SCPAIR_DW_TILE = 128 / 256 overrides.
 static int dw_tile_features(bool has_val) {
   static int w = -1;
   if (w < 0) {
@@ -853,7 +877,8 @@ static int dw_tile_features(bool has_val) {
     w = e ? atoi(e) : 0;
   }
   if (w == 128 || w == 256) return w;
-  return has_val ? 256 : 128;
+  (void)has_val;
+  return 128;
 }
 
 // smallest split-K factor scp_spmm_fwd_bf16 accepts for F features (its per-slab offset table holds PCH K-steps)
@@ -863,9 +888,10 @@ extern "C" int scp_spmm_fwd_bf16_min_split(int F) {
 }
 
 extern "C" int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
-                                 const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream_) {
+                                 const uint32_t* t_pk, const void* Wbf, long ldw, float* Y, long ldy, int nsplit, void* stream_) {
   SCP_CHECK(ncells > 0 && N > 0 && F > 0, SCP_ERR_ARG, "scp_spmm_fwd_bf16: sizes must be positive");
   SCP_CHECK(t_ptr && t_key && Wbf && Y, SCP_ERR_ARG, "scp_spmm_fwd_bf16: null pointer");
+  SCP_CHECK(!t_val || t_pk, SCP_ERR_ARG, "scp_spmm_fwd_bf16: value-carrying tile lists need the packed entries (t_pk) scp_tiles_build writes");
   SCP_CHECK(ldw % 8 == 0 && ldw >= F && ((uintptr_t)Wbf % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_fwd_bf16: shadow weights need a 16-byte aligned base and ld %% 8 == 0");
   static uint64_t done_v = 0, done_n = 0;
@@ -874,7 +900,7 @@ extern "C" int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr,
                  : set_smem((const void*)spmm_fwd_bf16_kernel<false>, smem, &done_n);
   if (rc) return rc;
   SpArgs g = {};
-  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
+  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.pk = t_pk; g.ncb = (ncells + 63) / 64;
   g.D = (const __bf16*)Wbf; g.ldd = ldw; g.C = Y; g.ldc = ldy;
   g.tiles_m = (ncells + 255) / 256; g.tiles_n = (N + 127) / 128;
   int ksteps = (F + 63) / 64;
@@ -896,9 +922,10 @@ extern "C" int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr,
 }
 
 extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
-                                const void* dYT, long ldt, float* dW, long ldw, void* stream_) {
+                                const uint32_t* t_pk, const void* dYT, long ldt, float* dW, long ldw, void* stream_) {
   SCP_CHECK(ncells > 0 && N > 0 && F > 0, SCP_ERR_ARG, "scp_spmm_dw_bf16: sizes must be positive");
   SCP_CHECK(t_ptr && t_key && dYT && dW, SCP_ERR_ARG, "scp_spmm_dw_bf16: null pointer");
+  SCP_CHECK(!t_val || t_pk, SCP_ERR_ARG, "scp_spmm_dw_bf16: value-carrying tile lists need the packed entries (t_pk) scp_tiles_build writes");
   SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_dw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
   SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16: more than %d cells per call unsupported",
@@ -909,7 +936,7 @@ extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, 
                  : set_smem((const void*)spmm_dw_bf16_kernel<false, false>, smem, &done_n);
   if (rc) return rc;
   SpArgs g = {};
-  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
+  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.pk = t_pk; g.ncb = (ncells + 63) / 64;
   g.D = (const __bf16*)dYT; g.ldd = ldt; g.C = dW; g.ldc = ldw;
   g.tiles_m = (N + 127) / 128; g.tiles_n = (F + 255) / 256; g.nsplit = 1;
   int grid = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
@@ -922,13 +949,16 @@ extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, 
 }
 
 extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key,
-                                      const float* t_val, const void* dYT, long ldt, float* W, long ldw, float* exp_avg,
+                                      const float* t_val, const uint32_t* t_pk, const void* dYT, long ldt, float* W, long ldw,
+                                      float* exp_avg,
                                       float* exp_avg_sq, void* W_bf16, long ld_bf16, float lr, float weight_decay,
                                       float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                                       float grad_scale, const float* bc_dev, void* stream_) {
   SCP_CHECK(ncells > 0 && N > 0 && F > 0, SCP_ERR_ARG, "scp_spmm_dw_adamw_bf16: sizes must be positive");
   SCP_CHECK(t_ptr && t_key && dYT && W && exp_avg && exp_avg_sq && W_bf16, SCP_ERR_ARG,
             "scp_spmm_dw_adamw_bf16: null pointer");
+  SCP_CHECK(!t_val || t_pk, SCP_ERR_ARG,
+            "scp_spmm_dw_adamw_bf16: value-carrying tile lists need the packed entries (t_pk) scp_tiles_build writes");
   SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_dw_adamw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
   SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: more than %d cells per call unsupported",
@@ -946,7 +976,7 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
                  : set_smem((const void*)spmm_dw_bf16_kernel<false, true>, smem, &done_n);
   if (rc) return rc;
   SpArgs g = {};
-  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
+  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.pk = t_pk; g.ncb = (ncells + 63) / 64;
   g.D = (const __bf16*)dYT; g.ldd = ldt; g.C = W; g.ldc = ldw;
   g.tiles_m = (N + 127) / 128; g.tiles_n = (F + 255) / 256; g.nsplit = 1;
   g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_sh = (__bf16*)W_bf16; g.adam_ldsh = ld_bf16;
@@ -980,9 +1010,11 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
 }
 
 extern "C" int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key,
-                                    const float* t_val, const void* dYT, long ldt, void* dW, long ldw, void* stream_) {
+                                    const float* t_val, const uint32_t* t_pk, const void* dYT, long ldt, void* dW, long ldw,
+                                    void* stream_) {
   SCP_CHECK(ncells > 0 && N > 0 && F > 0, SCP_ERR_ARG, "scp_spmm_dw_bf16_g16: sizes must be positive");
   SCP_CHECK(t_ptr && t_key && dYT && dW && ldw >= F, SCP_ERR_ARG, "scp_spmm_dw_bf16_g16: bad argument");
+  SCP_CHECK(!t_val || t_pk, SCP_ERR_ARG, "scp_spmm_dw_bf16_g16: value-carrying tile lists need the packed entries (t_pk) scp_tiles_build writes");
   SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_dw_bf16_g16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
   SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16_g16: more than %d cells per call unsupported",
@@ -993,7 +1025,7 @@ extern "C" int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_p
                  : set_smem((const void*)spmm_dw_bf16_kernel<false, false, true>, smem, &done_n);
   if (rc) return rc;
   SpArgs g = {};
-  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.ncb = (ncells + 63) / 64;
+  g.ncells = ncells; g.N = N; g.F = F; g.ptr = t_ptr; g.key = t_key; g.val = t_val; g.pk = t_pk; g.ncb = (ncells + 63) / 64;
   g.D = (const __bf16*)dYT; g.ldd = ldt; g.C = (float*)dW; g.ldc = ldw;
   g.tiles_m = (N + 127) / 128; g.tiles_n = (F + 255) / 256; g.nsplit = 1;
   int grid = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);

@@ -154,6 +154,13 @@ __global__ __launch_bounds__(1024) void tiles_scan_kernel(int32_t* __restrict__ 
   }
 }
 
+// packed entry of the bf16 first-layer kernels: (bf16 bits of the value, round to nearest even as the kernels' own
+// conversion did) << 16 | low 16 key bits (position inside any feature tile of up to 1024 features)
+__device__ __forceinline__ uint32_t tile_pack(int key, float v) {
+  const __bf16 b = (__bf16)v;
+  return ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16) | ((uint32_t)key & 0xffffu);
+}
+
 __global__ __launch_bounds__(256) void tiles_place_kernel(const int64_t* __restrict__ indptr,
                                                           const int32_t* __restrict__ indices,
                                                           const float* __restrict__ values,
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) void tiles_place_kernel(const int64_t* __restr
                                                           int nslice, const int32_t* __restrict__ bnd,
                                                           const int32_t* __restrict__ base_of /* scanned tot */,
                                                           int32_t* __restrict__ ptr, int32_t* __restrict__ key,
-                                                          float* __restrict__ val) {
+                                                          float* __restrict__ val, uint32_t* __restrict__ pk) {
   __shared__ int32_t cnt[TILE_MAX_SF];
   __shared__ int64_t row_e0[64];
   __shared__ int32_t row_lo[64], row_hi[64];
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256) void tiles_place_kernel(const int64_t* __restr
     const int e = row_lo[r] + lane;
     const bool ok = e < row_hi[r];
     c[k] = ok ? indices[row_e0[r] + e] : -1;
-    v[k] = (ok && val && values) ? values[row_e0[r] + e] : 1.f;
+    v[k] = (ok && (val || pk) && values) ? values[row_e0[r] + e] : 1.f;
   }
   // pass 1: per-feature counts
 #pragma unroll
@@ -243,6 +250,7 @@ __global__ __launch_bounds__(256) void tiles_place_kernel(const int64_t* __restr
       const int pos = base + atomicAdd(&cnt[c[k] - f0], 1);
       key[pos] = (c[k] << 6) | r;
       if (val) val[pos] = v[k];
+      if (pk) pk[pos] = tile_pack((c[k] << 6) | r, v[k]);
     }
   }
   for (int k = 0; k < 16; k++) {
@@ -251,7 +259,9 @@ __global__ __launch_bounds__(256) void tiles_place_kernel(const int64_t* __restr
       const int col = indices[row_e0[r] + e];
       const int pos = base + atomicAdd(&cnt[col - f0], 1);
       key[pos] = (col << 6) | r;
-      if (val) val[pos] = values ? values[row_e0[r] + e] : 1.f;
+      const float vv = values ? values[row_e0[r] + e] : 1.f;
+      if (val) val[pos] = vv;
+      if (pk) pk[pos] = tile_pack((col << 6) | r, vv);
     }
   }
 }
@@ -264,8 +274,8 @@ extern "C" long scp_tiles_ws_len(int B, int F) {
 }
 
 extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* rows,
-                               int B, int F, int32_t* ptr, int32_t* key, float* val, float* lib, int32_t* nnan,
-                               int32_t* ws, void* stream_) {
+                               int B, int F, int32_t* ptr, int32_t* key, float* val, uint32_t* pk, float* lib,
+                               int32_t* nnan, int32_t* ws, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(B > 0 && F > 0, SCP_ERR_ARG, "scp_tiles_build: B and F must be positive (%d,%d)", B, F);
   SCP_CHECK(indptr && indices && rows && ptr && key && ws, SCP_ERR_ARG, "scp_tiles_build: null pointer");
@@ -286,7 +296,7 @@ extern "C" int scp_tiles_build(const int64_t* indptr, const int32_t* indices, co
                      want_sum ? nnrow : (const int32_t*)nullptr, B, nnan);
   SCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(tiles_place_kernel, dim3(nslice, ncb), dim3(256), 0, stream, indptr, indices, values, rows, B, F,
-                     sf, nslice, bnd, tot, ptr, key, val);
+                     sf, nslice, bnd, tot, ptr, key, val, (val && values) ? pk : (uint32_t*)nullptr);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
@@ -320,8 +330,8 @@ extern "C" int scp_tiles_to_dense(int B, int F, const int32_t* ptr, const int32_
 //      counts, so the default is off): mode 1: v <- log1p(v); mode 2: v <- log1p(v * scale / lib[cell]) with lib the
 //      cell's library size.  Only the batch's own entries are touched; no normalised matrix is ever materialised. ----
 __global__ __launch_bounds__(256) void tiles_transform_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ key,
-                                                              float* __restrict__ val, int B, int F,
-                                                              const float* __restrict__ lib, int mode, float scale) {
+                                                              float* __restrict__ val, uint32_t* __restrict__ pk, int B,
+                                                              int F, const float* __restrict__ lib, int mode, float scale) {
   int cb = blockIdx.y;
   int e0 = ptr[(long)cb * F], e1 = ptr[(long)(cb + 1) * F];
   for (int e = e0 + blockIdx.x * 256 + threadIdx.x; e < e1; e += gridDim.x * 256) {
@@ -331,18 +341,20 @@ __global__ __launch_bounds__(256) void tiles_transform_kernel(const int32_t* __r
       float l = (c < B) ? lib[c] : 1.f;
       v = (l > 0.f) ? v * (scale / l) : v;
     }
-    val[e] = log1pf(v);
+    v = log1pf(v);
+    val[e] = v;
+    if (pk) pk[e] = tile_pack(key[e], v);
   }
 }
 
-extern "C" int scp_tiles_transform(int B, int F, const int32_t* ptr, const int32_t* key, float* val, const float* lib,
-                                   int mode, float scale, void* stream_) {
+extern "C" int scp_tiles_transform(int B, int F, const int32_t* ptr, const int32_t* key, float* val, uint32_t* pk,
+                                   const float* lib, int mode, float scale, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SCP_CHECK(B > 0 && F > 0 && ptr && key && val, SCP_ERR_ARG, "scp_tiles_transform: bad argument (values are required)");
   SCP_CHECK(mode == 1 || (mode == 2 && lib && scale > 0.f), SCP_ERR_ARG,
             "scp_tiles_transform: mode must be 1 (log1p) or 2 (log1p of library-size normalised counts, needs lib and scale > 0)");
   int ncb = (B + 63) / 64;
-  hipLaunchKernelGGL(tiles_transform_kernel, dim3(64, ncb), dim3(256), 0, stream, ptr, key, val, B, F, lib, mode, scale);
+  hipLaunchKernelGGL(tiles_transform_kernel, dim3(64, ncb), dim3(256), 0, stream, ptr, key, val, pk, B, F, lib, mode, scale);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

@@ -302,7 +302,7 @@ class FcnnLayerFn(torch.autograd.Function):
         slabs = torch.empty((nslab, Bn, H), dtype=torch.float32, device=dev)
         if use_bf:
             _lib.check(L.scp_spmm_fwd_bf16(Bn, H, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val),
-                                           shadow.data_ptr(), shadow.shape[1], slabs.data_ptr(), H, nsplit,
+                                           _lib.ptr(x.pk), shadow.data_ptr(), shadow.shape[1], slabs.data_ptr(), H, nsplit,
                                            _lib.stream()), "scp_spmm_fwd_bf16")
             xs = None
         elif sparse:
@@ -368,7 +368,7 @@ class FcnnLayerFn(torch.autograd.Function):
                     if tm is not None:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                    _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                    _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), _lib.ptr(t.pk),
                                                         dYT.data_ptr(), ldt, W.data_ptr(), Ftot, m_.data_ptr(),
                                                         v_.data_ptr(), sh_.data_ptr(), sh_.shape[1], *hp,
                                                         _lib.stream()), "scp_spmm_dw_adamw_bf16")
@@ -378,12 +378,12 @@ class FcnnLayerFn(torch.autograd.Function):
                 elif ctx.sink is not None:
                     # data parallel: dW goes to the exchange buffer as bf16; the optimiser reads it from there
                     dW = None
-                    _lib.check(L.scp_spmm_dw_bf16_g16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                    _lib.check(L.scp_spmm_dw_bf16_g16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), _lib.ptr(t.pk),
                                                       dYT.data_ptr(), ldt, ctx.sink.view.data_ptr(), Ftot,
                                                       _lib.stream()), "scp_spmm_dw_bf16_g16")
                     ctx.sink.written = True
                 else:
-                    _lib.check(L.scp_spmm_dw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val),
+                    _lib.check(L.scp_spmm_dw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), _lib.ptr(t.pk),
                                                   dYT.data_ptr(), ldt, dW.data_ptr(), Ftot, _lib.stream()),
                                "scp_spmm_dw_bf16")
             elif ctx.sparse:
@@ -568,7 +568,8 @@ class EncBranchesFn(torch.autograd.Function):
             W1 = P[g[0]][0]
             if use_bf:
                 sh = shadows[g[0]]
-                _lib.check(L.scp_spmm_fwd_bf16(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), sh.data_ptr(),
+                _lib.check(L.scp_spmm_fwd_bf16(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), _lib.ptr(x.pk),
+                                               sh.data_ptr(),
                                                sh.shape[1], slabs[gi].data_ptr(), Hg, nsplits[gi], stream),
                            "scp_spmm_fwd_bf16")
             else:
@@ -657,7 +658,7 @@ class EncBranchesFn(torch.autograd.Function):
                           dW3.view(N3s[i], H2s[i]) if N3s[i] else None, db3 if N3s[i] else None])
         _lib.check(L.scp_enc_tail_bwd(arr, nb, stream), "scp_enc_tail_bwd")
         # ---- first-layer weight gradient (and, where registered, the AdamW step in its epilogue) -------------------
-        tp, tk, tv = _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val)
+        tp, tk, tv, tpk = _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), _lib.ptr(t.pk)
         if not use_bf:
             for i in range(nb):
                 if need_w1[i]:
@@ -697,20 +698,20 @@ class EncBranchesFn(torch.autograd.Function):
                         if tm is not None:
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record()
-                        _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, Hu, F, tp, tk, tv, dyt_ptr, ldt, W1.data_ptr(), F,
+                        _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, W1.data_ptr(), F,
                                                             m_.data_ptr(), v_.data_ptr(), sh_.data_ptr(), sh_.shape[1],
                                                             *hp, stream), "scp_spmm_dw_adamw_bf16")
                         if tm is not None:
                             e1.record()
                             tm.append((e0, e1, Hu * F, int(t.nnz) * (8 if t.val is not None else 4) + 2 * Hu * ldt))
                     elif sk is not None:
-                        _lib.check(L.scp_spmm_dw_bf16_g16(Bn, Hu, F, tp, tk, tv, dyt_ptr, ldt, sk.view.data_ptr(), F, stream),
+                        _lib.check(L.scp_spmm_dw_bf16_g16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, sk.view.data_ptr(), F, stream),
                                    "scp_spmm_dw_bf16_g16")
                         for i in u:
                             cfg["br"][i]["sink"].written = True
                     else:
                         dW = torch.empty((Hu, F), dtype=torch.float32, device=dev)
-                        _lib.check(L.scp_spmm_dw_bf16(Bn, Hu, F, tp, tk, tv, dyt_ptr, ldt, dW.data_ptr(), F, stream),
+                        _lib.check(L.scp_spmm_dw_bf16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, dW.data_ptr(), F, stream),
                                    "scp_spmm_dw_bf16")
                         row_ = 0
                         for i in u:

@@ -169,6 +169,8 @@ class BatchTiles:
         self.ptr = torch.empty(L.scp_tiles_ptr_len(self.B, self.F), dtype=torch.int32, device=dev)
         self.key = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)
         self.val = None if csr.values is None else torch.empty(max(self.nnz, 1), dtype=torch.float32, device=dev)
+        # packed (bf16 value, low key bits) words: what the bf16 first-layer kernels read for value-carrying data
+        self.pk = None if csr.values is None else torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)
         tf = csr.transform
         need_lib = want_lib or (tf is not None and tf[0] == "log1p_norm")
         self.lib = torch.empty(self.B, dtype=torch.float32, device=dev) if need_lib else None
@@ -176,11 +178,11 @@ class BatchTiles:
         ws = torch.empty(L.scp_tiles_ws_len(self.B, self.F), dtype=torch.int32, device=dev)
         _lib.check(L.scp_tiles_build(_lib.ptr(csr.indptr), _lib.ptr(csr.indices), _lib.ptr(csr.values),
                                      _lib.ptr(rows_dev), self.B, self.F, _lib.ptr(self.ptr), _lib.ptr(self.key),
-                                     _lib.ptr(self.val), _lib.ptr(self.lib), _lib.ptr(self.nnan), _lib.ptr(ws),
-                                     _lib.stream()), "scp_tiles_build")
+                                     _lib.ptr(self.val), _lib.ptr(self.pk), _lib.ptr(self.lib), _lib.ptr(self.nnan),
+                                     _lib.ptr(ws), _lib.stream()), "scp_tiles_build")
         if tf is not None:
             _lib.check(L.scp_tiles_transform(self.B, self.F, _lib.ptr(self.ptr), _lib.ptr(self.key), _lib.ptr(self.val),
-                                             _lib.ptr(self.lib), 2 if tf[0] == "log1p_norm" else 1, tf[1],
+                                             _lib.ptr(self.pk), _lib.ptr(self.lib), 2 if tf[0] == "log1p_norm" else 1, tf[1],
                                              _lib.stream()), "scp_tiles_transform")
         self.csr = csr
 

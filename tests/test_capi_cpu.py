@@ -35,7 +35,7 @@ def test_argument_validation_without_gpu():
     assert L.scp_version() >= 1
     assert L.scp_gemm_nt(0, 4, 4, None, 1, 1, None, 1, 1, None, 1, None, 0, 1, 3, None) == -1
     assert b"positive" in L.scp_last_error()
-    assert L.scp_tiles_build(None, None, None, None, 4, 4, None, None, None, None, None, None, None) == -1
+    assert L.scp_tiles_build(None, None, None, None, 4, 4, None, None, None, None, None, None, None, None) == -1
     assert L.scp_dec_kp(40) == 48 and L.scp_dec_kp(9) == 16 and L.scp_dec_kp(50) == 64
     assert L.scp_dec_chunks(100000) == (100000 + 127) // 128      # chunks of DEC_NPT = 2 feature tiles of 64
     assert L.scp_tiles_ptr_len(130, 1000) == 3 * 1000 + 2
