@@ -172,27 +172,35 @@ static int launch_finish(FinishJobs& J, hipStream_t stream) {
 }
 
 
-extern "C" int scp_dec_chunks(int F) { return (F + DEC_NPT * FT - 1) / (DEC_NPT * FT); }
+static int dec_chunks_npt(int F, int npt) { return (F + npt * FT - 1) / (npt * FT); }
+extern "C" int scp_dec_chunks(int F) { return dec_chunks_npt(F, DEC_NPT); }
 extern "C" int scp_dec_kp(int K) { return K <= 16 ? 16 : (K <= 48 ? 48 : 64); }
 
-// cell blocks per workgroup: enough (chunk x cell-group) workgroups to fill the chip a few times over
-static int dec_cpg(int B, int F) {
-  int nchunk = scp_dec_chunks(F), ncb = (B + CB - 1) / CB;
+// Launch geometry of a pass: chunks of `npt` feature tiles x cell groups of `cpg` cell blocks -- enough workgroups
+// to fill the chip a few times over
+struct PassGeom { int nchunk, cpg, ncg; };
+static PassGeom pass_geom(int B, int F, int npt) {
+  PassGeom q;
+  q.nchunk = dec_chunks_npt(F, npt);
+  const int ncb = (B + CB - 1) / CB;
   static int target = 0;
   if (!target) {
     const char* e = getenv("SCPAIR_DEC_WGS");
     target = e ? atoi(e) : 2048;
     if (target < 1) target = 2048;
   }
-  int ncg = (target + nchunk - 1) / nchunk;
+  int ncg = (target + q.nchunk - 1) / q.nchunk;
   if (ncg > ncb) ncg = ncb;
   if (ncg < 1) ncg = 1;
-  return (ncb + ncg - 1) / ncg;
+  q.cpg = (ncb + ncg - 1) / ncg;
+  {
+    const char* e = getenv(npt == DEC_NPT ? "SCPAIR_DEC_CPG_TRAIN" : "SCPAIR_DEC_CPG_EVAL");   // experiments
+    if (e && atoi(e) > 0) q.cpg = atoi(e) < ncb ? atoi(e) : ncb;
+  }
+  q.ncg = (ncb + q.cpg - 1) / q.cpg;
+  return q;
 }
-static int dec_ncg(int B, int F) {
-  int ncb = (B + CB - 1) / CB, cpg = dec_cpg(B, F);
-  return (ncb + cpg - 1) / cpg;
-}
+static int dec_ncg(int B, int F) { return pass_geom(B, F, DEC_NPT).ncg; }
 
 static int check_common(const char* who, int B, int F, int K, const float* h, const float* W, const float* bias,
                         const void* ws) {
@@ -209,16 +217,23 @@ extern "C" long scp_dec_ws_floats(int B, int F, int K) {
   const long Bp = (B + CB - 1) / CB * CB;
   return nchunk * Bp * scp_dec_kp(K) + nchunk * (long)B * 2 + ncg * (long)F * K + 3 * ncg * (long)F;
 }
-extern "C" long scp_dec_ws_doubles(int B, int F) { return (long)scp_dec_chunks(F) * dec_ncg(B, F) + 8; }
+extern "C" long scp_dec_ws_doubles(int B, int F) {
+  const PassGeom t = pass_geom(B, F, DEC_NPT), e = pass_geom(B, F, DEC_NPT_EVAL);
+  const long nt = (long)t.nchunk * t.ncg, ne = (long)e.nchunk * e.ncg;
+  return (nt > ne ? nt : ne) + 8;
+}
 
 struct DecPlan {
-  int nchunk, KP, cpg, ncg;
+  int nchunk, KP, cpg, ncg;     // training passes
+  PassGeom ev;                  // passes without gradients
   float *dh_slab, *row_slab, *dW_slab, *db_slab, *dfs_slab, *dth_slab;
 };
 
 static DecPlan make_plan(DecArgs& g, float* ws_f, float* dW, long lddw, float* db, float* dfs, float* dtheta) {
   DecPlan p;
-  p.nchunk = scp_dec_chunks(g.F); p.KP = scp_dec_kp(g.K); p.cpg = dec_cpg(g.B, g.F); p.ncg = dec_ncg(g.B, g.F);
+  const PassGeom tg = pass_geom(g.B, g.F, DEC_NPT);
+  p.nchunk = tg.nchunk; p.KP = scp_dec_kp(g.K); p.cpg = tg.cpg; p.ncg = tg.ncg;
+  p.ev = pass_geom(g.B, g.F, DEC_NPT_EVAL);
   p.dh_slab = ws_f;
   p.row_slab = ws_f ? p.dh_slab + (long)p.nchunk * ((g.B + CB - 1) / CB * CB) * p.KP : nullptr;
   p.dW_slab = ws_f ? p.row_slab + (long)p.nchunk * g.B * 2 : nullptr;
@@ -268,11 +283,13 @@ extern "C" int scp_ber_dec_bce(int train, int B, int F, int K, const float* h, l
   g.lrow = lrow; g.lrow_n = lrow_n; g.t_ptr = t_ptr; g.t_key = t_key; g.t_val = t_val; g.nnan = nnan; g.gout = gout;
   g.loss_part = ws_d;
   DecPlan p = make_plan(g, ws_f, dW, lddw, db, fs ? dfs : nullptr, nullptr);
-  int nblk = p.nchunk * p.ncg;
-  rc = train ? dec_dispatch<MODE_BER_TRAIN>(g, ns, p.nchunk, stream) : dec_dispatch<MODE_BER_EVAL>(g, ns, p.nchunk, stream);
+  const int nchunk = train ? p.nchunk : p.ev.nchunk;
+  const int nblk = nchunk * (train ? p.ncg : p.ev.ncg);
+  if (!train) g.cpg = p.ev.cpg;
+  rc = train ? dec_dispatch<MODE_BER_TRAIN>(g, ns, nchunk, stream) : dec_dispatch<MODE_BER_EVAL>(g, ns, nchunk, stream);
   if (rc) return rc;
   FinishJobs J = {};
-  J.nchunk = p.nchunk; J.B = B;
+  J.nchunk = nchunk; J.B = B;
   J.loss_part = ws_d; J.nblk = nblk; J.n_total = (double)B * (double)F; J.nnan = nnan; J.loss = loss;
   if (train) {
     add_feature_jobs(J, p, g, dW, lddw, db, fs ? dfs : nullptr, nullptr);
@@ -303,26 +320,27 @@ extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, lon
   g.theta_param = theta_param; g.lrow = lrow; g.lrow_n = B; g.t_ptr = t_ptr; g.t_key = t_key; g.t_val = t_val;
   g.gout = gout; g.loss_part = ws_d;
   DecPlan p = make_plan(g, ws_f, dW, lddw, db, fs ? dfs : nullptr, theta_param ? dtheta : nullptr);
-  int nblk = p.nchunk * p.ncg;
+  const int nblk = p.ev.nchunk * p.ev.ncg;
   float* lse = rowbuf;
   float* T = rowbuf + B;
   // pass 1: row log-sum-exp
-  rc = dec_dispatch<MODE_NB_STATS>(g, ns, p.nchunk, stream);
+  g.cpg = p.ev.cpg;
+  rc = dec_dispatch<MODE_NB_STATS>(g, ns, p.ev.nchunk, stream);
   if (rc) return rc;
   {
     FinishJobs J = {};
-    J.nchunk = p.nchunk; J.B = B;
+    J.nchunk = p.ev.nchunk; J.B = B;
     J.row_slab = p.row_slab; J.row_mode = 1; J.row_scale = 1.f; J.row_out0 = lse; J.n_rows = (B + 63) / 64;
     rc = launch_finish(J, stream);
     if (rc) return rc;
   }
   // pass 2: loss and T
   g.rowlse = lse;
-  rc = dec_dispatch<MODE_NB_LOSS>(g, ns, p.nchunk, stream);
+  rc = dec_dispatch<MODE_NB_LOSS>(g, ns, p.ev.nchunk, stream);
   if (rc) return rc;
   {
     FinishJobs J = {};
-    J.nchunk = p.nchunk; J.B = B;
+    J.nchunk = p.ev.nchunk; J.B = B;
     J.loss_part = ws_d; J.nblk = nblk; J.n_total = (double)B * (double)F; J.loss = loss;
     if (train) {
       J.row_slab = p.row_slab; J.row_mode = (dlat && lat) ? 2 : 0; J.row_scale = -1.f / ((float)B * (float)F);
@@ -334,6 +352,7 @@ extern "C" int scp_nb_dec_ll(int train, int B, int F, int K, const float* h, lon
   if (!train) return SCP_OK;
   // pass 3: gradients
   g.rowT = T;
+  g.cpg = p.cpg;
   rc = dec_dispatch<MODE_NB_GRAD>(g, ns, p.nchunk, stream);
   if (rc) return rc;
   {

@@ -718,7 +718,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 }
 
 
-#define DEC_NPT 2
+#define DEC_NPT 2        // feature tiles per chunk, training passes (a dW accumulator tile per feature tile stays in registers)
+#define DEC_NPT_EVAL 4   // passes without gradients: the h block is staged and the row reductions run once per 4 tiles
+template <int MODE> constexpr int dec_npt() { return (MODE == MODE_BER_TRAIN || MODE == MODE_NB_GRAD) ? DEC_NPT : DEC_NPT_EVAL; }
 
 template <int NS, int KP>
 static size_t dec_smem() {
@@ -732,9 +734,9 @@ static int dec_launch_v(const DecArgs& g, int grid, hipStream_t stream) {
   const int ncg_ = (ncb_ + g.cpg - 1) / g.cpg;
   static uint64_t attr_done = 0;
   size_t smem = dec_smem<NS, KP>();
-  int rc_ = scp_set_smem((const void*)dec_kernel<NS, KP, DEC_NPT, MODE, VEC>, smem, &attr_done);
+  int rc_ = scp_set_smem((const void*)dec_kernel<NS, KP, dec_npt<MODE>(), MODE, VEC>, smem, &attr_done);
   if (rc_) return rc_;
-  hipLaunchKernelGGL((dec_kernel<NS, KP, DEC_NPT, MODE, VEC>), dim3(grid, ncg_), dim3(256), smem, stream, g);
+  hipLaunchKernelGGL((dec_kernel<NS, KP, dec_npt<MODE>(), MODE, VEC>), dim3(grid, ncg_), dim3(256), smem, stream, g);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }
