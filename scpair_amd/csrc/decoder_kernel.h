@@ -360,31 +360,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       const bool ber_fast = IS_BER && (f0 + FT <= g.F) && (c0 + CB <= g.B) && (tflag == 0);
       if (ber_fast) {
         float su = 0.f, sd = 0.f;
-#if defined(DEC_EXP) && DEC_EXP == 2
-#pragma unroll
-        for (int e = 0; e < 16; e++) { dzv[e] = acc[e] * inv_n; lsum += acc[e]; }
-#elif defined(DEC_EXP) && DEC_EXP == 1
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int cl = ti * 32 + acc_row(e, lane);
-          float ex = (acc[e] + bcol) * (acc[e] + bcol);
-          float px = (1.f + ex) * 0.5f;
-          float sr = rowv[cl];
-          float q = px * sr * fcol;
-          float omq = 1.f - q;
-          float yv = ytile[cl * FT + fl];
-          float arg = (yv == 0.f) ? omq : q;
-          lsum -= fmaxf(arg + 1.f, -100.f);
-          if (TRAIN) {
-            float u = (q - yv) * (fmaxf(q * omq, 1e-12f) * 0.25f) * inv_n * q;     // dL/dq * q
-            float d = u * (1.f - px);
-            dzv[e] = d;
-            racc0[e] += u * (1.f - sr);
-            su += u;
-            sd += d;
-          }
-        }
-#else
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int cl = ti * 32 + acc_row(e, lane);
@@ -404,7 +379,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             sd += d;
           }
         }
-#endif
         if (TRAIN) {
           dfs_acc[0] += su * (1.f - fcol);
           db_acc[0] += sd;
