@@ -515,28 +515,30 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
       // EPB row segments of the three streams in flight per lane before the first use: with one workgroup per CU the
       // epilogue's HBM rate is set by the bytes each CU keeps outstanding
       f4 pp[EPB], mm[EPB], vv[EPB];
+      // unpredicated (rows / columns past the end read a clamped, valid address; only the stores are predicated): the
+      // loads and the updates below form one straight line, so each row is processed when ITS loads have landed
+      // (counted waits) instead of after all of them
+      const int nc = col_ok ? n : max(g.F - 4, 0);
 #pragma unroll
       for (int u = 0; u < EPB; u++) {
-        int m = m0 + (pass + u) * 8 + rw;
-        if (col_ok && m < g.N) {
-          long o = (long)m * g.ldc + n;
-          pp[u] = __builtin_nontemporal_load((const f4*)(g.C + o));
-          mm[u] = __builtin_nontemporal_load((const f4*)(g.adam_m + o));
-          vv[u] = __builtin_nontemporal_load((const f4*)(g.adam_v + o));
-        }
+        const int m = min(m0 + (pass + u) * 8 + rw, g.N - 1);
+        const long o = (long)m * g.ldc + nc;
+        pp[u] = __builtin_nontemporal_load((const f4*)(g.C + o));
+        mm[u] = __builtin_nontemporal_load((const f4*)(g.adam_m + o));
+        vv[u] = __builtin_nontemporal_load((const f4*)(g.adam_v + o));
       }
 #pragma unroll
       for (int u = 0; u < EPB; u++) {
         int row = (pass + u) * 8 + rw;
         int m = m0 + row;
-        if (col_ok && m < g.N) {
-          f4 gg = *(const f4*)&gt[row * GLD + c4];
-          float pa[4], ma[4], va[4];
+        f4 gg = *(const f4*)&gt[row * GLD + c4];
+        float pa[4], ma[4], va[4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            pa[k] = pp[u][k]; ma[k] = mm[u][k]; va[k] = vv[u][k];
-            adamw_update(hy, pa[k], gg[k], ma[k], va[k]);
-          }
+        for (int k = 0; k < 4; k++) {
+          pa[k] = pp[u][k]; ma[k] = mm[u][k]; va[k] = vv[u][k];
+          adamw_update(hy, pa[k], gg[k], ma[k], va[k]);
+        }
+        if (col_ok && m < g.N) {
           long o = (long)m * g.ldc + n;
           f4 po = {pa[0], pa[1], pa[2], pa[3]}, mo = {ma[0], ma[1], ma[2], ma[3]}, vo = {va[0], va[1], va[2], va[3]};
           __builtin_nontemporal_store(po, (f4*)(g.C + o));
@@ -781,28 +783,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       // EPB row segments of the three streams in flight per lane before the first use: with one workgroup per CU the
       // epilogue's HBM rate is set by the bytes each CU keeps outstanding
       f4 pp[EPB], mm[EPB], vv[EPB];
+      // unpredicated (rows / columns past the end read a clamped, valid address; only the stores are predicated): the
+      // loads and the updates below form one straight line, so each row is processed when ITS loads have landed
+      // (counted waits) instead of after all of them
+      const int nc = col_ok ? n : max(g.F - 4, 0);
 #pragma unroll
       for (int u = 0; u < EPB; u++) {
-        int m = m0 + (pass + u) * 8 + rw;
-        if (col_ok && m < g.N) {
-          long o = (long)m * g.ldc + n;
-          pp[u] = __builtin_nontemporal_load((const f4*)(g.C + o));
-          mm[u] = __builtin_nontemporal_load((const f4*)(g.adam_m + o));
-          vv[u] = __builtin_nontemporal_load((const f4*)(g.adam_v + o));
-        }
+        const int m = min(m0 + (pass + u) * 8 + rw, g.N - 1);
+        const long o = (long)m * g.ldc + nc;
+        pp[u] = __builtin_nontemporal_load((const f4*)(g.C + o));
+        mm[u] = __builtin_nontemporal_load((const f4*)(g.adam_m + o));
+        vv[u] = __builtin_nontemporal_load((const f4*)(g.adam_v + o));
       }
 #pragma unroll
       for (int u = 0; u < EPB; u++) {
         int row = (pass + u) * 8 + rw;
         int m = m0 + row;
-        if (col_ok && m < g.N) {
-          f4 gg = *(const f4*)&gt[row * GLD + c4];
-          float pa[4], ma[4], va[4];
+        f4 gg = *(const f4*)&gt[row * GLD + c4];
+        float pa[4], ma[4], va[4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            pa[k] = pp[u][k]; ma[k] = mm[u][k]; va[k] = vv[u][k];
-            adamw_update(hy, pa[k], gg[k], ma[k], va[k]);
-          }
+        for (int k = 0; k < 4; k++) {
+          pa[k] = pp[u][k]; ma[k] = mm[u][k]; va[k] = vv[u][k];
+          adamw_update(hy, pa[k], gg[k], ma[k], va[k]);
+        }
+        if (col_ok && m < g.N) {
           long o = (long)m * g.ldc + n;
           f4 po = {pa[0], pa[1], pa[2], pa[3]}, mo = {ma[0], ma[1], ma[2], ma[3]}, vo = {va[0], va[1], va[2], va[3]};
           __builtin_nontemporal_store(po, (f4*)(g.C + o));
