@@ -33,7 +33,21 @@ struct SpArgs {
   float* adam_m; float* adam_v; __bf16* adam_sh; long adam_ldsh;
   float lr, wd, b1, b2, eps, bc1, bc2, gscale;
   const float* bc_dev;       // optional device words {bias_corr1, bias_corr2} (HIP-graph replays), else bc1 / bc2
+#ifdef SPMM_PROF
+  unsigned long long* prof;  // diagnostic build only: per-phase timestamps of one wave of the forward kernel
+#endif
 };
+#ifdef SPMM_PROF
+#define SP_MARK(m) do { if (prof_on) g.prof[(long)i * 8 + (m)] = clock64(); } while (0)
+static unsigned long long* sp_prof_dev = nullptr;
+extern "C" int scp_spmm_prof_read(unsigned long long* out, int n) {
+  if (!sp_prof_dev) return -1;
+  hipDeviceSynchronize();
+  return (int)hipMemcpy(out, sp_prof_dev, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
+}
+#else
+#define SP_MARK(m) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint4 ld16(const __bf16* p, bool ok) {
   uint4 z = {0u, 0u, 0u, 0u};
@@ -86,6 +100,9 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
 
   // sparse side: 4 cell blocks, 128 threads each
   const int cbl = tid >> 7, tl = tid & 127;
+#ifdef SPMM_PROF
+  const bool prof_on = (tid == 0) && (blockIdx.x == 64) && g.prof;
+#endif
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
     constexpr int s1 = (s + 1) % 3, s2 = (s + 2) % 3;
     const __bf16* Ar = As + s * ASZ;
     const __bf16* Br = Bs + (i & 1) * BSZ;
+    SP_MARK(0);
     bf16x8 af[4][2], bfr[4][2];
 #pragma unroll
     for (int kk = 0; kk < 4; kk++)
@@ -232,15 +250,21 @@ __global__ __launch_bounds__(512) void spmm_fwd_bf16_kernel(SpArgs g) {
         for (int jj = 0; jj < 2; jj++) acc[q][jj] = mfma32(af[kk][q], bfr[kk][jj], acc[q][jj]);
     };
     // ---- operands of step i+1 (stage s1) -----------------------------------------------------------------------
+    SP_MARK(1);
     if (FULL || i + 1 < nstep) stage_out(breg[s1], ekey[s1], p0[s1], p1[s1], i + 1, skey[s1]);
+    SP_MARK(2);
     mfma_group(0);
     mfma_group(1);
+    SP_MARK(3);
     // ---- loads of step i+4 into the stage just drained; restore the buffer of step i-1 for step i+2 -----------
     if (FULL || i + 4 < nstep) prefetch(breg[s1], ekey[s1], p0[s1], p1[s1], i + 4);
+    SP_MARK(4);
     mfma_group(2);
     if (FULL || (i >= 1 && i + 2 < nstep)) unscatter(i - 1, skey[s2]);
     mfma_group(3);
+    SP_MARK(5);
     __syncthreads();
+    SP_MARK(6);
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
@@ -917,6 +941,11 @@ extern "C" int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr,
             "scp_spmm_fwd_bf16: %d K-steps per slab exceed %d; use nsplit >= scp_spmm_fwd_bf16_min_split(F)", per, PCH);
   int units = g.tiles_n * g.nsplit;
   int grid = 8 * g.tiles_m * ((units + 7) / 8);
+#ifdef SPMM_PROF
+  if (!sp_prof_dev) hipMalloc(&sp_prof_dev, sizeof(unsigned long long) * 8 * 4096);
+  hipMemsetAsync(sp_prof_dev, 0, sizeof(unsigned long long) * 8 * 4096, (hipStream_t)stream_);
+  g.prof = sp_prof_dev;
+#endif
   if (t_val)
     hipLaunchKernelGGL(spmm_fwd_bf16_kernel<true>, dim3(grid), dim3(512), smem, (hipStream_t)stream_, g);
   else
