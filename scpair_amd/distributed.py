@@ -51,6 +51,23 @@ class GradSync:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def gather_rows(self, t):
+        """All-gather of one small 1-D tensor per rank -> [world, n] in rank order (the same on every rank).  Same host
+        detour as _sum for backends other than nccl."""
+        src = t.detach()
+        if self._backend != "nccl" and src.is_cuda:
+            src = src.cpu()
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src.contiguous(), group=self.group)
+        return torch.stack(parts).to(t.device)
+
+    def share_of(self, n_valid, device):
+        """This rank's share n_r / n_total of a step's valid label elements (one small SUM all-reduce): the weight its
+        loss carries in the global-batch loss.  A device scalar."""
+        nv = torch.as_tensor(n_valid, dtype=torch.float64, device=device).reshape(1).clone()
+        tot = self._sum(nv.clone())
+        return (nv / tot).to(torch.float32).reshape(())
+
     def broadcast(self, tensors, src=0):
         for t in tensors:
             t = t.data if hasattr(t, "data") else t

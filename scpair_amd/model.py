@@ -828,6 +828,8 @@ class scPair_object():
         """Data-parallel tail of one optimisation step: backward on this rank's shard (loss None: empty shard), the
         gradient exchange, the identical AdamW step on every rank.  Returns the global-batch loss."""
         optimizer.zero_grad()
+        if ops.bn_sync_active():        # BatchNorm's backward sums weigh the ranks like the loss does
+            ops.set_bn_sync_weight(self.grad_sync.share_of(n_valid, self.device))
         if loss is not None:
             loss.backward()
         params = [p for g in optimizer.param_groups for p in g['params']]
@@ -837,9 +839,17 @@ class scPair_object():
         return gl
 
     def _check_dp(self, *modules):
-        if self.grad_sync is not None and any(isinstance(m, nn.BatchNorm1d) for mod in modules for m in mod.modules()):
-            raise NotImplementedError("data-parallel training with batchnorm=True needs synchronised batch statistics, "
-                                      "which are not implemented: use batchnorm=False (the constructor default)")
+        """Data-parallel training of modules with BatchNorm1d: remember that they have such layers; the loops then switch
+        the global-batch statistics on per step (_bn_step)."""
+        self._dp_has_bn = self.grad_sync is not None and any(isinstance(m, nn.BatchNorm1d) for mod in modules
+                                                             for m in mod.modules())
+
+    def _bn_step(self, empty_somewhere):
+        """Before a data-parallel step's forward: BatchNorm statistics over the global batch (ops.set_bn_sync).  Off for a
+        step in which some rank's shard is empty (a last global batch smaller than the world): that rank runs no forward
+        and could not join the layers' collectives; the other ranks use their own statistics for that one step."""
+        if getattr(self, "_dp_has_bn", False):
+            ops.set_bn_sync(None if empty_somewhere else self.grad_sync)
 
     def train_predicting_networks(self, train_data_dict, val_data_dict, test_data_dict, batch_replay=None):
         """model.py:603-812.  `batch_replay`: optional {direction_index: [row-id arrays]} to replay a recorded batch
@@ -895,6 +905,7 @@ class scPair_object():
                     empty_somewhere = False
                     if self.grad_sync is not None:
                         empty_somewhere = self.grad_sync.some_rank_empty(len(rows))
+                        self._bn_step(empty_somewhere)
                         rows = self.grad_sync.shard(rows)
                         if len(rows) == 0:            # global batch smaller than the world: join the collectives only
                             step_losses.append(self._dp_step(None, 0.0, optimizer, True))
@@ -941,6 +952,7 @@ class scPair_object():
                 torch.save(decoder_dict[key], self.save_path + '/decoder_' + input_modality + '_to_' + output_modality + '.pt')
             self._say(f"Completed training for {input_modality} to {output_modality}")
         self.encoder_dict, self.decoder_dict = encoder_dict, decoder_dict
+        ops.set_bn_sync(None)
         return encoder_dict, decoder_dict
 
     def _train_step(self, tx, ty, lib, encoder, decoder, optimizer, dist, cov, some_rank_empty=False):
@@ -991,6 +1003,7 @@ class scPair_object():
                     if self.grad_sync is not None:
                         # data parallel: this rank's slice of the global batch, count-weighted gradient exchange
                         empty_somewhere = self.grad_sync.some_rank_empty(len(idx))
+                        self._bn_step(empty_somewhere)
                         idx = torch.from_numpy(self.grad_sync.shard(idx.numpy()))
                         if len(idx) == 0:
                             hist["train_loss"].append(self._dp_step(None, 0.0, optimizer, True))
@@ -1031,6 +1044,7 @@ class scPair_object():
                 torch.save(mapping_dict[key], self.save_path + '/mapping_' + input_modality + '_to_' + output_modality + '.pt')
             self._say(f"Completed mapping training for {input_modality} to {output_modality}")
         self.mapping_dict = mapping_dict
+        ops.set_bn_sync(None)
         return mapping_dict
 
     def _augment_covariates(self, unimodal_scobj, unimodal_cov, n_uni, n_cov):
@@ -1110,6 +1124,7 @@ class scPair_object():
                 empty_somewhere = False
                 if self.grad_sync is not None:
                     empty_somewhere = self.grad_sync.some_rank_empty(len(rows))
+                    self._bn_step(empty_somewhere)
                     rows = self.grad_sync.shard(rows)
                     if len(rows) == 0:
                         self._dp_step(None, 0.0, optimizer, True)
@@ -1149,4 +1164,5 @@ class scPair_object():
             if csr is None:
                 continue
             augment_emb[name + f'_{split}'] = self._encode(self.augment_encoder_ckpt, csr, cv).cpu().numpy()
+        ops.set_bn_sync(None)
         return self.augment_encoder_dict, augment_emb

@@ -812,6 +812,97 @@ class BatchNormFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None, None, None
 
 
+# ---- BatchNorm under data parallelism: batch statistics over the GLOBAL batch -------------------------------------
+# The trainers slice every global batch by rank; with per-rank statistics a BatchNorm layer would see a different batch
+# than the single-process run.  set_bn_sync(GradSync) makes training-mode batch_norm() combine the ranks' statistics
+# (each rank's two-pass mean / M2 and row count, all-gathered and merged in rank order with the parallel-variance
+# formula) and its backward exchange the two per-feature sums the input gradient needs.
+_bn_sync = {"sync": None, "w": None}
+
+
+def set_bn_sync(sync):
+    """`sync`: a distributed.GradSync (every rank must then run the same BatchNorm layers in the same order) or None."""
+    _bn_sync["sync"], _bn_sync["w"] = sync, None
+
+
+def bn_sync_active():
+    return _bn_sync["sync"] is not None
+
+
+def set_bn_sync_weight(w):
+    """This rank's share n_r / n_total of the step's label elements (GradSync.share_of), set before backward(): the
+    ranks' losses enter the global-batch loss with these weights, and so do their terms in BatchNorm's backward sums."""
+    _bn_sync["w"] = w
+
+
+def combine_bn_stats(rows, H):
+    """rows: [world, 2H + 1] = per rank (mean[H] | M2[H] | n).  Returns the global (mean, biased variance, N):
+    M2 = sum_r M2_r + sum_r n_r (mean_r - mean)^2.  Pure tensor arithmetic, identical on every rank."""
+    n = rows[:, 2 * H].double()
+    N = n.sum()
+    mr, m2r = rows[:, :H].double(), rows[:, H:2 * H].double()
+    mean = (mr * n[:, None]).sum(0) / N
+    m2 = m2r.sum(0) + (n[:, None] * (mr - mean) ** 2).sum(0)
+    return mean.float(), (m2 / N).float(), N.float()
+
+
+class SyncBatchNormFn(torch.autograd.Function):
+    """BatchNormFn with the statistics of the global batch.  forward: local (mean, M2, n) -> all-gather -> global mean /
+    variance -> the normalisation kernel run with them (its 'given statistics' mode) -> running statistics updated with
+    the global values.  backward: the kernel's given-statistics mode yields g*rstd*dy' and this rank's sums
+    (sum dy', sum dy'*xhat); the sums are weighted by this rank's loss share w_r, all-reduced, and the two mean terms of
+    the training-mode gradient are subtracted:  dx = g*rstd*(dy' - (S1 + xhat*S2) / (N*w_r))."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps, p_drop, seed):
+        L = _lib.lib()
+        sync = _bn_sync["sync"]
+        x = _f32c(x)
+        _lib.require_cuda(x)
+        B, H = x.shape
+        mean_r = x.mean(0)
+        m2_r = (x - mean_r).square().sum(0)
+        rows = sync.gather_rows(torch.cat([mean_r, m2_r, x.new_full((1,), float(B))]))
+        mean, var, N = combine_bn_stats(rows, H)
+        y = torch.empty_like(x)
+        smean, rstd = _empty((H,), x), _empty((H,), x)
+        seed_dev = _seed_dev() if p_drop > 0 else None
+        _lib.check(L.scp_bn_fwd(x.data_ptr(), H, B, H, _lib.ptr(gamma), _lib.ptr(beta), mean.data_ptr(), var.data_ptr(), 0,
+                                0.0, float(eps), float(p_drop), int(seed), seed_dev, smean.data_ptr(), rstd.data_ptr(),
+                                y.data_ptr(), H, _lib.stream()), "scp_bn_fwd")
+        if run_mean is not None:
+            run_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            run_var.mul_(1.0 - momentum).add_(var * (N / torch.clamp(N - 1.0, min=1.0)), alpha=momentum)
+        ctx.seed_dev, ctx.sync = seed_dev, sync
+        ctx.save_for_backward(x, gamma, smean, rstd, N)
+        ctx.cfg = (float(p_drop), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, gamma, mean, rstd, N = ctx.saved_tensors
+        p_drop, seed = ctx.cfg
+        dy = _f32c(dy)
+        B, H = x.shape
+        dx = torch.empty_like(x)
+        dg, db = _empty((H,), x), _empty((H,), x)
+        _lib.check(L.scp_bn_bwd(dy.data_ptr(), H, x.data_ptr(), H, B, H, _lib.ptr(gamma), mean.data_ptr(), rstd.data_ptr(), 0,
+                                p_drop, seed, ctx.seed_dev, dx.data_ptr(), H, dg.data_ptr(), db.data_ptr(), _lib.stream()),
+                   "scp_bn_bwd")
+        w = _bn_sync["w"]
+        if w is None:
+            raise RuntimeError("synchronised BatchNorm backward needs this rank's loss share: call "
+                               "ops.set_bn_sync_weight(GradSync.share_of(n_valid, device)) before backward()")
+        S = ctx.sync._sum(torch.cat([db, dg]) * w)
+        coef = rstd / (N * w) if gamma is None else gamma * rstd / (N * w)
+        xhat = (x - mean) * rstd
+        dx -= coef * (S[:H] + xhat * S[H:])
+        if gamma is None:
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None
+
+
 def batch_norm(x, bn, training, p_drop=0.0, seed=0):
     """nn.BatchNorm1d `bn` applied by the HIP kernel (batch statistics + in-place running-statistics update when
     training and tracking, running statistics otherwise), followed by dropout p_drop."""
@@ -821,6 +912,9 @@ def batch_norm(x, bn, training, p_drop=0.0, seed=0):
     mom = bn.momentum
     if mom is None:                               # cumulative moving average
         mom = 1.0 / float(bn.num_batches_tracked) if (training and bn.num_batches_tracked is not None) else 0.0
+    if training and _bn_sync["sync"] is not None:
+        return SyncBatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                     bn.running_var if bn.track_running_stats else None, mom, bn.eps, p_drop, seed)
     return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                              bn.running_var if bn.track_running_stats else None, use_batch, mom, bn.eps, p_drop, seed)
 

@@ -214,3 +214,60 @@ def test_exchange_with_ragged_and_empty_shards(n_rows):
         for ref, got in zip((W1, b1, W2), (grads[0], grads[1], grads[3])):
             np.testing.assert_allclose(got, ref.grad.numpy(), rtol=1e-4, atol=1e-5)
         assert abs(gl - float(loss)) < 1e-5 * abs(float(loss))
+
+
+def _bn_worker(rank, world, port, out):
+    """The statistics half of synchronised BatchNorm on two gloo ranks (the kernels themselves need a GPU: the full
+    forward / backward is covered by tests/test_dp_trainer_gpu.py): per-rank (mean, M2, n) gathered and merged must
+    equal the statistics of the whole batch, and the backward's formula with all-reduced sums must equal autograd
+    through torch's batch_norm on the whole batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scpair_amd.distributed import GradSync
+    from scpair_amd.ops import combine_bn_stats
+    sync = GradSync()
+    g = torch.Generator().manual_seed(5)
+    H, eps = 7, 1e-5
+    X = torch.randn(11, H, generator=g) * 3 + 1
+    dY = torch.randn(11, H, generator=g)
+    gamma = torch.rand(H, generator=g) + 0.5
+    rows = sync.shard(np.arange(11))                         # 6 + 5 rows
+    x = X[rows]
+    mean_r = x.mean(0)
+    st = sync.gather_rows(torch.cat([mean_r, (x - mean_r).square().sum(0), x.new_full((1,), float(len(rows)))]))
+    mean, var, N = combine_bn_stats(st, H)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    # global loss = mean over ALL rows of sum(dY * y): rank r's own loss is the mean over its rows, its share w_r = n_r / N
+    w = sync.share_of(float(len(rows)), torch.device("cpu"))
+    dy = dY[rows] / len(rows)                                # gradient of this rank's own loss
+    xhat = (x - mean) * rstd
+    S = sync._sum(torch.cat([dy.sum(0), (dy * xhat).sum(0)]) * w)
+    dx = gamma * rstd * dy - gamma * rstd / (N * w) * (S[:H] + xhat * S[H:])
+    out.put((rank, rows, mean.numpy(), var.numpy(), (dx * w).numpy()))      # w_r * local gradient = global gradient
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bn_statistics_and_backward_over_two_ranks_equal_the_whole_batch():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    g = torch.Generator().manual_seed(5)
+    H, eps = 7, 1e-5
+    X = (torch.randn(11, H, generator=g) * 3 + 1).requires_grad_(True)
+    dY = torch.randn(11, H, generator=g)
+    gamma = torch.rand(H, generator=g) + 0.5
+    y = torch.nn.functional.batch_norm(X, None, None, gamma, torch.zeros(H), True, 0.1, eps)
+    ((dY * y).sum() / 11).backward()
+    np.testing.assert_allclose(res[0][2], X.detach().mean(0).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(res[0][3], X.detach().var(0, unbiased=False).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=0)          # identical on both ranks
+    dx = np.concatenate([res[0][4], res[1][4]])
+    np.testing.assert_allclose(dx, X.grad.numpy(), rtol=2e-4, atol=1e-6)

@@ -20,14 +20,14 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _train(grad_sync, batch, epochs, with_mapping, precision="fp32"):
+def _train(grad_sync, batch, epochs, with_mapping, precision="fp32", batchnorm=False):
     import scpair_amd as S
     from tests.test_trajectory_gpu import _dicts
     d = U.load("traj_nb_ber")
     c = U.cfg(d, "cfg")
     tr, va, te = _dicts(c, d)
     obj = S.scPair_object(None, cov=None, modalities=c["modalities"], SEED=0, hidden_layer=c["hidden"], dropout_rate=0.0,
-                          batchnorm=False, layernorm=True, batch_size=batch, max_epochs=epochs,
+                          batchnorm=batchnorm, layernorm=True, batch_size=batch, max_epochs=epochs,
                           device=torch.device("cuda:0"), save_model=False, zero_inflated=c["zero_inflated"],
                           verbose=False, grad_sync=grad_sync, use_mixed_precision=(precision == "bf16"))
     obj.train_predicting_networks(tr, va, te)
@@ -37,14 +37,14 @@ def _train(grad_sync, batch, epochs, with_mapping, precision="fp32"):
     return {k: (list(map(float, v["train_loss"])), list(map(float, v["val_loss"]))) for k, v in obj.history.items()}
 
 
-def _worker(rank, world, port, out, batch, epochs, with_mapping, precision="fp32", compress=False):
+def _worker(rank, world, port, out, batch, epochs, with_mapping, precision="fp32", compress=False, batchnorm=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=True)           # a stuck collective ends the rank with a traceback
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from scpair_amd.distributed import GradSync
-    hist = _train(GradSync(compress=compress), batch, epochs, with_mapping, precision)
+    hist = _train(GradSync(compress=compress), batch, epochs, with_mapping, precision, batchnorm)
     faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         out.put(hist)
@@ -52,12 +52,12 @@ def _worker(rank, world, port, out, batch, epochs, with_mapping, precision="fp32
     dist.destroy_process_group()
 
 
-def _run_two_ranks(batch, epochs, with_mapping=False, precision="fp32", compress=False):
+def _run_two_ranks(batch, epochs, with_mapping=False, precision="fp32", compress=False, batchnorm=False):
     world = 2
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out, batch, epochs, with_mapping, precision, compress))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, batch, epochs, with_mapping, precision, compress, batchnorm))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -113,3 +113,18 @@ def test_two_rank_trainer_bf16_exchange_buffer():
     h2 = _run_two_ranks(64, 2, precision="bf16", compress=True)
     h1 = _train(None, 64, 2, False, precision="bf16")
     _compare(h2, h1, 2e-2)
+
+
+def test_two_rank_trainer_with_batchnorm_uses_global_batch_statistics():
+    """batchnorm=True under data parallelism: the BatchNorm layers normalise with the statistics of the GLOBAL batch
+    (ops.SyncBatchNormFn: per-rank mean / M2 all-gathered and merged, the backward's two per-feature sums all-reduced
+    with the ranks' loss shares), so the two-rank run follows the single-process run of the same configuration (itself
+    pinned to the reference by tests/golden/traj_nb_ber_bn.npz in test_trajectory_gpu.py).  409-row batches over 410
+    cells: the one-cell last batch leaves rank 1 empty and is the step that falls back to per-rank statistics."""
+    b = U.cfg(U.load("traj_nb_ber"), "cfg")["batch"]
+    h2 = _run_two_ranks(b, 2, batchnorm=True)
+    h1 = _train(None, b, 2, False, batchnorm=True)
+    _compare(h2, h1, 5e-4)
+    h2 = _run_two_ranks(409, 2, batchnorm=True)
+    h1 = _train(None, 409, 2, False, batchnorm=True)
+    _compare(h2, h1, 5e-4)
