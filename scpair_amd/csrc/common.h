@@ -105,6 +105,19 @@ __device__ __forceinline__ void adamw_update(const AdamHyper& h, float& p, float
   p -= h.step_size * (m / denom);
 }
 
+// The same update with the hardware square root and reciprocal (v_sqrt_f32 / v_rcp_f32, ~1 ulp each) instead of the
+// correctly rounded sqrtf and division, whose expansions are two thirds of the exact update's ~37 instructions: for
+// the epilogue of the first-layer weight-gradient kernel (precision mode 'bf16'), which spends a third of its
+// vector-issue time here.  Relative difference to adamw_update per step: ~2e-7 of the step, i.e. ~1e-9 of a weight.
+__device__ __forceinline__ void adamw_update_fast(const AdamHyper& h, float& p, float g, float& m, float& v) {
+  float gk = g * h.grad_scale;
+  p *= h.decay;
+  m = m + (gk - m) * (1.f - h.b1);
+  v = v * h.b2 + gk * gk * (1.f - h.b2);
+  float denom = __builtin_amdgcn_sqrtf(v) * h.inv_sqrt_bc2 + h.eps;
+  p -= h.step_size * (m * __builtin_amdgcn_rcpf(denom));
+}
+
 // ---- wave / block reductions -------------------------------------------------------------
 // Cross-lane moves on the vector ALU (no LDS round trip like __shfl_xor's ds_bpermute): DPP within a row of 16 lanes,
 // gfx950's permlane swaps across rows.  CTRL: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1]

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           pa[k] = pp[u][k]; ma[k] = mm[u][k]; va[k] = vv[u][k];
-          adamw_update(hy, pa[k], gg[k], ma[k], va[k]);
+          adamw_update_fast(hy, pa[k], gg[k], ma[k], va[k]);
         }
         if (col_ok && m < g.N) {
           long o = (long)m * g.ldc + n;
@@ -599,6 +599,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   const int wm = wave & 1, wn = wave >> 1;
 
   int b = blockIdx.x;
+#ifdef SPMM_PROF
+  const bool prof_on = (threadIdx.x == 0) && g.prof && (blockIdx.x % 97 == 5);
+  const long prof_slot = (blockIdx.x / 97) % 500;
+#define DW_MARK(m) do { if (prof_on) g.prof[prof_slot * 8 + (m)] = clock64(); } while (0)
+  DW_MARK(0);
+#else
+#define DW_MARK(m) do { } while (0)
+#endif
   int xcd = b & 7, j = b >> 3;
   int m_tile = j % g.tiles_m;
   int unit = (j / g.tiles_m) * 8 + xcd;
@@ -748,6 +756,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     mfma_group(3);
     __syncthreads();
   };
+  DW_MARK(1);
   using T_ = std::true_type;
   using F_ = std::false_type;
   using S0 = std::integral_constant<int, 0>;
@@ -768,6 +777,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     if (i + 2 < nstep) k_step(F_{}, S2{}, i + 2);
   }
 
+  DW_MARK(2);
   if constexpr (!ADAM) {
 #pragma unroll
     for (int i2 = 0; i2 < 2; i2++)
@@ -796,6 +806,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         for (int e = 0; e < 16; e++)
           gt[(wm * 64 + i2 * 32 + acc_row(e, lane)) * GLD + wn * 64 + jj * 32 + r] = acc[i2][jj][e];
     __syncthreads();
+    DW_MARK(3);
     typedef float f4 __attribute__((ext_vector_type(4)));
     const float bc1 = g.bc_dev ? g.bc_dev[0] : g.bc1, bc2 = g.bc_dev ? g.bc_dev[1] : g.bc2;
     const AdamHyper hy = adam_hyper(g.lr, g.wd, g.b1, g.b2, g.eps, bc1, bc2, g.gscale);
@@ -828,7 +839,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           pa[k] = pp[u][k]; ma[k] = mm[u][k]; va[k] = vv[u][k];
-          adamw_update(hy, pa[k], gg[k], ma[k], va[k]);
+          adamw_update_fast(hy, pa[k], gg[k], ma[k], va[k]);
         }
         if (col_ok && m < g.N) {
           long o = (long)m * g.ldc + n;
@@ -844,6 +855,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       }
     }
   }
+  DW_MARK(5);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1015,6 +1027,11 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
   g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_sh = (__bf16*)W_bf16; g.adam_ldsh = ld_bf16;
   g.lr = lr; g.wd = weight_decay; g.b1 = beta1; g.b2 = beta2; g.eps = eps; g.bc1 = bias_corr1; g.bc2 = bias_corr2;
   g.gscale = grad_scale; g.bc_dev = bc_dev;
+#ifdef SPMM_PROF
+  if (!sp_prof_dev) hipMalloc(&sp_prof_dev, sizeof(unsigned long long) * 8 * 4096);
+  hipMemsetAsync(sp_prof_dev, 0, sizeof(unsigned long long) * 8 * 4096, (hipStream_t)stream_);
+  g.prof = sp_prof_dev;
+#endif
   if (dw_tile_features(t_val != nullptr) == 128) {
     // two workgroups of 128 x 128 tiles per CU: the AdamW epilogue of one overlaps the K loop of the other
     static uint64_t d128_v = 0, d128_n = 0;
