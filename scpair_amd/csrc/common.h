@@ -283,13 +283,23 @@ __device__ __forceinline__ float digam2(float y, float th) {
   return digammaf_pos(y + th) - digammaf_pos(th);
 }
 
-// counter-based RNG for dropout masks: one 32-bit hash per (seed, element index); reproducible in backward
+// counter-based RNG for dropout masks: one 32-bit hash per (seed, element index); reproducible in backward.
+// The seed goes through a 64-bit mixer (splitmix64 finaliser) once -- it is uniform over the launch, so this runs on
+// the scalar unit -- and every element then costs two 32-bit multiply rounds (the 'lowbias32' integer hash) instead of
+// three 64-bit multiplies: full-width integer multiplies issue at a quarter of the vector rate, and the fused tail
+// kernels hash ~1800 elements per cell in each direction.
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  uint64_t z = seed + 0x632BE59BD9B4E019ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  uint32_t x = (uint32_t)idx + (uint32_t)z + (uint32_t)(idx >> 32) * 0x85EBCA6Bu;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x ^ (uint32_t)(z >> 32);
 }
 // dropout seed of a launch = by-value base + an optional device-resident per-step offset (HIP-graph replays: the graph
 // bakes the by-value arguments, the offset word is rewritten before every replay by scp_step_state_set)
