@@ -203,3 +203,64 @@ class GradSync:
     def reduce_scalars(self, num, den):
         v = self._sum(torch.stack([num.double(), den.double()]))
         return v[0], v[1]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Feature-sharded first layer (prototype of DESIGN.md section 7): every rank owns a COLUMN block W[:, f0:f1) of a
+# wide first-layer weight (and its AdamW state), instead of a full replica whose gradient is all-reduced.
+#   forward : every rank multiplies the GLOBAL batch's columns [f0, f1) with its block -> partial Y [B_global, H];
+#             one SUM all-reduce of Y (B_global x H floats: 3.7 MB per 1024 cells at H = 900) gives the pre-activations;
+#             each rank keeps the rows of its own cell shard.
+#   backward: each rank's dY rows, weighted by its share n_r / n_total of the step's label elements, are all-gathered
+#             into dY of the global batch; dW of the own column block = dY_global^T X[:, f0:f1) is then complete on the
+#             rank: no gradient exchange for the wide weights (C2: 272-524 MB per direction and step become 2 x 3.7 MB
+#             per 1024 cells), and the optimiser traffic and state of those weights divide by the number of ranks.
+# The products themselves are callables supplied by the caller: ops.fcnn_layer / the bf16 tile-list kernels on the GPU
+# (tests/test_dp_trainer_gpu.py), plain matmuls in the world-size-2 gloo test of the algebra on the CPU -- this module
+# holds no compute path of its own.
+# ---------------------------------------------------------------------------------------------------------
+def shard_bounds(n: int, world: int):
+    """[lo, hi) of every rank's slice under np.array_split(range(n), world) (GradSync.shard's rule)."""
+    base, extra = divmod(n, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+class _FeatureShardedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W_block, x_cols, sync, local_fwd, local_dw, share):
+        y = local_fwd(x_cols, W_block)                      # [B_global, H]: this rank's columns only
+        y = sync._sum(y.contiguous())
+        B = y.shape[0]
+        lo, hi = shard_bounds(B, sync.world)[sync.rank]
+        ctx.x_cols, ctx.sync, ctx.local_dw, ctx.share, ctx.B = x_cols, sync, local_dw, share, B
+        ctx.wshape = tuple(W_block.shape)
+        return y[lo:hi].clone()
+
+    @staticmethod
+    def backward(ctx, dy):
+        sync, B = ctx.sync, ctx.B
+        bounds = shard_bounds(B, sync.world)
+        width = max(hi - lo for lo, hi in bounds)
+        mine = torch.zeros((width, dy.shape[1]), dtype=dy.dtype, device=dy.device)
+        lo, hi = bounds[sync.rank]
+        mine[:hi - lo] = dy * ctx.share                    # this rank's loss enters the global loss with weight n_r / n_total
+        parts = sync.gather_rows(mine.reshape(-1)).reshape(sync.world, width, dy.shape[1])
+        dy_g = torch.cat([parts[r, :h - l] for r, (l, h) in enumerate(bounds)], dim=0)
+        dW = ctx.local_dw(ctx.x_cols, dy_g, ctx.wshape)     # complete gradient of the own column block
+        return dW, None, None, None, None, None
+
+
+def feature_sharded_first_layer(W_block, x_cols, sync: GradSync, local_fwd, local_dw, share):
+    """Rows [lo, hi) (this rank's cell shard) of X @ W^T for the global batch, W split by columns over the ranks.
+
+    W_block : this rank's [H, F_r] parameter; its .grad after backward() is the gradient of the GLOBAL-batch loss
+              (do not hand it to GradSync.exchange: nothing is left to sum, and the share is already applied)
+    x_cols  : the global batch restricted to this rank's columns, in whatever form the callables take
+    local_fwd(x_cols, W_block) -> [B_global, H];  local_dw(x_cols, dY_global, W_block.shape) -> [H, F_r]
+    share   : this rank's n_r / n_total of the step's valid label elements (GradSync.share_of)"""
+    return _FeatureShardedFn.apply(W_block, x_cols, sync, local_fwd, local_dw, share)

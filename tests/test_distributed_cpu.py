@@ -271,3 +271,46 @@ def test_bn_statistics_and_backward_over_two_ranks_equal_the_whole_batch():
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=0)          # identical on both ranks
     dx = np.concatenate([res[0][4], res[1][4]])
     np.testing.assert_allclose(dx, X.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+def _fs_worker(rank, world, port, out):
+    """Feature-sharded first layer on two gloo ranks with plain matmuls as the local products: rows of Y and the
+    gradient of each rank's column block must equal autograd on the whole batch and the whole weight."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scpair_amd.distributed import GradSync, feature_sharded_first_layer, shard_bounds
+    sync = GradSync()
+    g = torch.Generator().manual_seed(11)
+    B, F, H = 11, 30, 5                                      # 6 + 5 rows; columns 0:15 / 15:30
+    X = torch.randn(B, F, generator=g); W = torch.randn(H, F, generator=g); T = torch.randn(B, H, generator=g)
+    f0, f1 = shard_bounds(F, world)[rank]
+    lo, hi = shard_bounds(B, world)[rank]
+    Wb = torch.nn.Parameter(W[:, f0:f1].clone())
+    share = sync.share_of(float(hi - lo), torch.device("cpu"))
+    y = feature_sharded_first_layer(Wb, X[:, f0:f1], sync, lambda x, w: x @ w.t(), lambda x, dy, shp: dy.t() @ x, share)
+    loss = ((torch.tanh(y) - T[lo:hi]) ** 2).mean()         # this rank's own loss: mean over its rows
+    loss.backward()
+    out.put((rank, y.detach().numpy(), Wb.grad.numpy(), (f0, f1), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_feature_sharded_first_layer_equals_the_whole_batch():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fs_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    g = torch.Generator().manual_seed(11)
+    B, F, H = 11, 30, 5
+    X = torch.randn(B, F, generator=g); W = torch.randn(H, F, generator=g).requires_grad_(True); T = torch.randn(B, H, generator=g)
+    Y = X @ W.t()
+    ((torch.tanh(Y) - T) ** 2).mean().backward()            # the global-batch loss: mean over ALL rows
+    for rank, y, gw, (f0, f1), (lo, hi) in res:
+        np.testing.assert_allclose(y, Y.detach().numpy()[lo:hi], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(gw, W.grad.numpy()[:, f0:f1], rtol=1e-5, atol=1e-7)

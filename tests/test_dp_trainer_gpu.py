@@ -128,3 +128,85 @@ def test_two_rank_trainer_with_batchnorm_uses_global_batch_statistics():
     h2 = _run_two_ranks(409, 2, batchnorm=True)
     h1 = _train(None, 409, 2, False, batchnorm=True)
     _compare(h2, h1, 5e-4)
+
+
+def _fs_gpu_worker(rank, world, port, out):
+    """Feature-sharded first layer with the HIP tile-list kernels as the local products (fp32-equivalent mode)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    import scipy.sparse as sp
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import scpair_amd as S
+    from scpair_amd import ops
+    from scpair_amd.distributed import GradSync, feature_sharded_first_layer, shard_bounds
+    dev = torch.device("cuda:0")
+    sync = GradSync()
+    rng = np.random.default_rng(3)
+    B, F, H = 150, 700, 72
+    X = sp.random(B, F, density=0.06, format="csr", random_state=rng, dtype=np.float32)
+    X.data = np.ceil(X.data * 5).astype(np.float32)
+    g = torch.Generator().manual_seed(3)
+    W = torch.randn(H, F, generator=g) * 0.1
+    T = torch.randn(B, H, generator=g)
+    f0, f1 = shard_bounds(F, world)[rank]
+    lo, hi = shard_bounds(B, world)[rank]
+    tiles = S.BatchTiles(S.DeviceCSR.from_scipy(X[:, f0:f1].tocsr(), dev), np.arange(B), want_lib=False)
+    Wb = torch.nn.Parameter(W[:, f0:f1].contiguous().to(dev))
+
+    def local_fwd(t, w):
+        return ops.fcnn_layer(t, None, w, None, None, None, 1.0)
+
+    def local_dw(t, dy, shp):
+        wt = Wb.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            o = ops.fcnn_layer(t, None, wt, None, None, None, 1.0)
+        o.backward(dy)
+        return wt.grad
+
+    share = sync.share_of(float(hi - lo), dev)
+    y = feature_sharded_first_layer(Wb, tiles, sync, local_fwd, local_dw, share)
+    loss = ((torch.tanh(y) - T[lo:hi].to(dev)) ** 2).mean()
+    loss.backward()
+    faulthandler.cancel_dump_traceback_later()
+    out.put((rank, y.detach().cpu().numpy(), Wb.grad.cpu().numpy(), (f0, f1), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_feature_sharded_first_layer_on_the_tile_list_kernels():
+    """Prototype of the feature-sharded first layer (scpair_amd/distributed.py): two ranks, each owning half of the
+    columns of W and a tile list of the global batch restricted to them; rows of Y and each block's gradient against a
+    dense fp32 computation of the whole batch (the kernels' fp32-equivalent mode: 1e-4)."""
+    import scipy.sparse as sp
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fs_gpu_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [out.get(timeout=110) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    rng = np.random.default_rng(3)
+    B, F, H = 150, 700, 72
+    X = sp.random(B, F, density=0.06, format="csr", random_state=rng, dtype=np.float32)
+    X.data = np.ceil(X.data * 5).astype(np.float32)
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(H, F, generator=g) * 0.1).requires_grad_(True)
+    T = torch.randn(B, H, generator=g)
+    Y = torch.from_numpy(X.toarray()) @ W.t()
+    ((torch.tanh(Y) - T) ** 2).mean().backward()
+    for rank, y, gw, (f0, f1), (lo, hi) in res:
+        ref_y, ref_g = Y.detach().numpy()[lo:hi], W.grad.numpy()[:, f0:f1]
+        assert float(np.abs(y - ref_y).max()) < 1e-4 * float(np.abs(ref_y).max()), rank
+        assert float(np.abs(gw - ref_g).max()) < 1e-4 * float(np.abs(ref_g).max()), rank
