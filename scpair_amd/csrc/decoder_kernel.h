@@ -223,6 +223,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       evl[i] = e_val[ec];                         // no use of the loaded values here (it would wait for the loads)
     }
   };
+  auto clear_labels = [&]() {
+    float4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < CB * FT / 4; idx += 256) ((float4*)ytile)[idx] = z4;
+    if (tid == 0) tflag = 0;
+  };
+  if (TRAIN && NEED_LABELS) clear_labels();      // first iteration; the barrier at its top orders it before the scatter
   const int ntl = min(NPT, (g.F - f_chunk0 + FT - 1) / FT);     // valid feature tiles of this chunk (>= 1)
   if (cb_beg < cb_end) {
     load_h(cb_beg * CB);
@@ -280,11 +286,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       put_rows(wreg, WB, WT);
       const float bias_c = bias_n, fs_c = fs_n, th_c = th_n;      // this tile's scalars, before the next prefetch
       if (NEED_LABELS) {
-        float4 z4 = {0.f, 0.f, 0.f, 0.f};
-        for (int idx = tid; idx < CB * FT / 4; idx += 256) ((float4*)ytile)[idx] = z4;
-        if (tid == 0) tflag = 0;
-        PROF_MARK(2);
-        __syncthreads();
+        if (!TRAIN) {
+          // (the training passes clear the tile right after the barrier that ends their epilogue, see below: the
+          // barrier at the top of the iteration then separates the clear from the scatter and this one is not needed)
+          clear_labels();
+          PROF_MARK(2);
+          __syncthreads();
+        }
         PROF_MARK(3);
         bool odd = false;
 #pragma unroll
@@ -531,6 +539,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         PROF_MARK(8);
         __syncthreads();
         PROF_MARK(9);
+        if (NEED_LABELS) clear_labels();          // every wave is past its epilogue: the label tile is free again
         // ---- dW tile += dZ^T h ; dh block += dZ W -----------------------------------------------
         const int mi = wave & 1, nj = wave >> 1;
         if (nj < NTK) {
