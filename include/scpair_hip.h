@@ -89,6 +89,19 @@ int scp_gemm_nt(int M, int N, int K, const float* A, long a_row_stride, long a_k
  * three row-major nn.Linear cases */
 int scp_gemm_lib_bf16(int ta, int tb, int m, int n, int k, const void* A_bf16, long lda, const void* B_bf16, long ldb,
                       float* C, long ldc, void* stream);
+/* The same wide layers on the hand-written MFMA kernel (csrc/wgemm.hip), replacing torch's addmm behind nn.Linear
+ * (model.py:228,255-256; pairedVAE.py:111-119) forward, input gradient and weight gradient:
+ *   C[m][n] = sum_k A(m,k) B(n,k) (+ bias[n]) (set to zero where mask[m][n] <= 0: the backward of a relu on the input)
+ * bf16 operands, fp32 accumulate/output.  a_col = 0: A is stored [M][lda] (k contiguous); 1: stored [K][lda] (m
+ * contiguous); b_col likewise for B over n.  Leading dimensions are multiples of 8 >= the column count rounded up to 8,
+ * pointers 16-byte aligned, the whole [rows][ld] extent readable, and the pad columns of a k-contiguous operand zero
+ * (scp_cast_bf16 and the AdamW shadow write them so).  Shapes that do not fill the CUs evenly run as
+ * scp_gemm_bf16_nsplit K-ranges into the caller's workspace ws (scp_gemm_bf16_ws_floats floats, 0 when not needed),
+ * added in a fixed order: results are bitwise reproducible.  bias / mask may be null. */
+int scp_gemm_bf16_nsplit(int M, int N, int K);
+long scp_gemm_bf16_ws_floats(int M, int N, int K, long ldc);
+int scp_gemm_bf16(int a_col, int b_col, int M, int N, int K, const void* A_bf16, long lda, const void* B_bf16, long ldb,
+                  float* C, long ldc, const float* bias, const void* mask_bf16, long ldm, float* ws, void* stream);
 int scp_slab_reduce(const float* slabs, long slab_stride, int nslab, int rows, int cols, long ld,
                     const float* bias, float* out, long ldo, void* stream);
 int scp_colsum(const float* X, long ld, int rows, int cols, float* out, float* partials_ws /* [32*cols] */,

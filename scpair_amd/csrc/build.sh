@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wno-u
 OBJ="$HERE/build"
 mkdir -p "$OBJ"
 pids=()
-for f in capi gemm libgemm spmm_bf16 tiles norm_act enc_tail adamw elementwise raw_rows eval_metrics decoder decoder_ber_ns1 decoder_ber_ns3 decoder_nb_ns1 decoder_nb_ns3; do
+for f in capi gemm libgemm wgemm spmm_bf16 tiles norm_act enc_tail adamw elementwise raw_rows eval_metrics decoder decoder_ber_ns1 decoder_ber_ns3 decoder_nb_ns1 decoder_nb_ns3; do
   if [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/decoder_kernel.h" -nt "$OBJ/$f.o" ] || [ "$ROOT/include/scpair_hip.h" -nt "$OBJ/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)

@@ -1,0 +1,323 @@
+// Wide dense GEMM of the plain nn.Linear layers whose two dimensions are both large: the ZINB zero-inflation layer
+// G x G (reference model.py:228,255-256) and the VAE's 900 <-> G layers (pairedVAE.py:111-119), precision mode 'bf16'.
+//
+//   C[m][n] = sum_k A(m,k) B(n,k)  (+ bias[n])  (zero where mask[m][n] <= 0)       bf16 operands, fp32 accumulate / output
+//
+// Each operand is either stored "row" ([rows][ld], k contiguous) or "col" ([K][ld], rows contiguous), so the three
+// products of a Linear layer run on the operands as they lie in memory, without a transposed copy:
+//   y  = x W^T   : A = x  row, B = W row        dx = dy W : A = dy row, B = W col        dW = dy^T x : A = dy col, B = x col
+//
+// Workgroup: 256 threads = 2 x 2 waves, tile 256 x 256 x 64, every wave 128 x 128 = 4 x 4 accumulators of the
+// 32x32x16 bf16 MFMA (256 accumulator registers; one wave per SIMD, 512 registers per lane).  Operand tiles go
+// global -> registers (16-byte buffer loads, the range check supplies the zeros of ragged edges) -> LDS, two LDS
+// stages of 64 KB, one barrier per K-step: the next step's global loads are in flight while this step's 64 MFMAs run.
+//   row image  [256][64]  : 128-byte rows, 16-byte chunk c of row r at chunk c ^ (r & 7); read with ds_read_b128
+//   col image  [64][256]  : 512-byte rows, 64-byte segment s of row k at segment s ^ (k & 3); read with the
+//                           transposing ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16 lanes), conflict-free
+// Work split: tiles x nsplit K-ranges so that the launch fills the 256 CUs evenly (1024 x 20 k is 316 tiles = 1.23
+// rounds; four K-ranges make it 4.94 rounds of a quarter each); the K-ranges write fp32 slabs which a second kernel
+// adds in a fixed order, together with bias and mask (bitwise reproducible: no atomics).  Consecutive workgroup ids
+// go round-robin over the 8 XCDs, so the id is remapped to give each XCD a contiguous run of tiles (the tiles that
+// share a B tile sit next to each other in one L2).
+#include "common.h"
+#include "scpair_hip.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int STAGE_BYTES = (TM + TN) * TK * 2;   // 64 KB
+
+struct WgArgs {
+  const __bf16* A;
+  const __bf16* B;
+  float* C;            // output, or slabs [nsplit][M][ldc] when nsplit > 1
+  const float* bias;   // direct mode only
+  const __bf16* mask;  // direct mode only
+  long lda, ldb, ldc, ldm;
+  int M, N, K;
+  int tiles_m, tiles_n, nsplit, ksteps_per_split;
+  unsigned a_bytes, b_bytes;
+};
+
+typedef __attribute__((ext_vector_type(4))) short short4_;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ u32x4 ld128(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+}
+
+// LDS byte offsets inside an operand image
+__device__ __forceinline__ int row_off(int r, int ch) { return r * 128 + ((ch ^ (r & 7)) << 4); }
+__device__ __forceinline__ int col_off(int k, int m) { return k * 512 + ((((m >> 5) ^ (k & 3))) << 6) + ((m & 31) << 1); }
+
+template <bool COL>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char* img, int r0, int s, int lane) {
+  if (!COL) {
+    const int r = r0 + (lane & 31), ch = 2 * s + (lane >> 5);
+    return *(const bf16x8*)(img + row_off(r, ch));
+  } else {
+    // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block; lane i receives column i
+    const int g = lane >> 5, mb = ((lane >> 4) & 1) * 16, q = (lane & 15) >> 2, p = lane & 3;
+    const int k = 16 * s + 8 * g + q, m = r0 + mb + 4 * p;
+    typedef __attribute__((address_space(3))) short4_ lds_s4;
+    short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(img + col_off(k, m)));
+    short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(img + col_off(k + 4, m)));
+    union { short4_ h[2]; bf16x8 v; } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+  }
+}
+
+template <bool A_COL, bool B_COL, bool DIRECT>
+__global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware id: ids b, b+8, b+16.. run on one XCD -> give them consecutive tiles
+  const int total = g.tiles_m * g.tiles_n * g.nsplit;
+  const int per_xcd = (total + 7) >> 3;
+  const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (lid >= total) return;
+  const int tm = lid % g.tiles_m;
+  const int tn = (lid / g.tiles_m) % g.tiles_n;
+  const int z = lid / (g.tiles_m * g.tiles_n);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int nk_all = (g.K + TK - 1) / TK;
+  const int kt0 = z * g.ksteps_per_split;
+  const int kt1 = min(nk_all, kt0 + g.ksteps_per_split);
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)g.b_bytes, 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;     // beyond any operand (host checks bytes < 2 GiB): the load returns zeros
+
+  // chunk c = tid + 256 i.  row image: row (tid >> 3) + 32 i, chunk tid & 7; col image: k row (tid >> 5) + 8 i,
+  // chunk tid & 31: the global offset and the LDS offset of chunk i are those of chunk 0 plus i times a constant
+  const int Kp = (g.K + 7) & ~7;
+  const int rA = A_COL ? (tid >> 5) : (tid >> 3), cA = A_COL ? (tid & 31) : (tid & 7);
+  const int rB = B_COL ? (tid >> 5) : (tid >> 3), cB = B_COL ? (tid & 31) : (tid & 7);
+  const unsigned baseA = A_COL ? (unsigned)(((long)rA * g.lda + m0 + 8 * cA) * 2) : (unsigned)(((long)(m0 + rA) * g.lda + 8 * cA) * 2);
+  const unsigned baseB = B_COL ? (unsigned)(((long)rB * g.ldb + n0 + 8 * cB) * 2) : (unsigned)(((long)(n0 + rB) * g.ldb + 8 * cB) * 2);
+  const unsigned stepA = (unsigned)((A_COL ? 8 : 32) * g.lda * 2), stepB = (unsigned)((B_COL ? 8 : 32) * g.ldb * 2);
+  const int ldsA0 = A_COL ? col_off(rA, 8 * cA) : row_off(rA, cA);
+  const int ldsB0 = B_COL ? col_off(rB, 8 * cB) : row_off(rB, cB);
+  const bool colokA = !A_COL || (m0 + 8 * cA < g.lda), colokB = !B_COL || (n0 + 8 * cB < g.ldb);
+
+  u32x4 ra[8], rb[8];
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * TK;
+    const unsigned kA = A_COL ? (unsigned)((long)k0 * g.lda * 2) : (unsigned)k0 * 2u;
+    const unsigned kB = B_COL ? (unsigned)((long)k0 * g.ldb * 2) : (unsigned)k0 * 2u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const bool va = A_COL ? (colokA && k0 + rA + 8 * i < g.K) : (m0 + rA + 32 * i < g.M && k0 + 8 * cA < Kp);
+      const bool vb = B_COL ? (colokB && k0 + rB + 8 * i < g.K) : (n0 + rB + 32 * i < g.N && k0 + 8 * cB < Kp);
+      ra[i] = ld128(rsA, va ? baseA + kA + stepA * i : OOR);
+      rb[i] = ld128(rsB, vb ? baseB + kB + stepB * i : OOR);
+    }
+  };
+  auto store_tiles = [&](int stage) {
+    unsigned char* ia = smem + stage * STAGE_BYTES;
+    unsigned char* ib = ia + TM * TK * 2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      *(u32x4*)(ia + ldsA0 + 4096 * i) = ra[i];
+      *(u32x4*)(ib + ldsB0 + 4096 * i) = rb[i];
+    }
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  if (kt0 < kt1) {
+    load_tiles(kt0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int stage = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) load_tiles(kt + 1);
+    const unsigned char* ia = smem + stage * STAGE_BYTES;
+    const unsigned char* ib = ia + TM * TK * 2;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = read_frag<A_COL>(ia, wm * 128 + 32 * i, s, lane);
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = read_frag<B_COL>(ib, wn * 128 + 32 * j, s, lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+    if (more) store_tiles(stage ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: accumulator element e of lane l is row acc_row(e, l), column l & 31 of its 32 x 32 tile
+  float* Cz = g.C + (DIRECT ? 0 : (long)z * g.M * g.ldc);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int n = n0 + wn * 128 + 32 * j + (lane & 31);
+    if (n >= g.N) continue;
+    const float bn = (DIRECT && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = m0 + wm * 128 + 32 * i + acc_row(e, lane);
+        if (m < g.M) {
+          float v = acc[i][j][e] + bn;
+          if (DIRECT && g.mask && !((float)g.mask[(long)m * g.ldm + n] > 0.f)) v = 0.f;
+          Cz[(long)m * g.ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// C = sum of the K-range slabs in slab order, + bias, masked
+__global__ __launch_bounds__(256) void wgemm_reduce_kernel(const float* __restrict__ slabs, int nsplit, int M, int N, long ldc,
+                                                            const float* __restrict__ bias, const __bf16* __restrict__ mask,
+                                                            long ldm, float* __restrict__ C) {
+  const long n4 = (N + 3) / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * n4) return;
+  const int m = (int)(i / n4), c = (int)(i % n4) * 4;
+  const long slab = (long)M * ldc;
+  const float* p = slabs + (long)m * ldc + c;
+  if (c + 3 < N && (ldc & 3) == 0) {
+    f32x4 s = *(const f32x4*)p;
+    for (int zz = 1; zz < nsplit; zz++) s += *(const f32x4*)(p + zz * slab);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (bias) s[t] += bias[c + t];
+      if (mask && !((float)mask[(long)m * ldm + c + t] > 0.f)) s[t] = 0.f;
+    }
+    *(f32x4*)(C + (long)m * ldc + c) = s;
+  } else {
+    for (int t = 0; t < 4 && c + t < N; t++) {
+      float s = p[t];
+      for (int zz = 1; zz < nsplit; zz++) s += p[t + zz * slab];
+      if (bias) s += bias[c + t];
+      if (mask && !((float)mask[(long)m * ldm + c + t] > 0.f)) s = 0.f;
+      C[(long)m * ldc + c + t] = s;
+    }
+  }
+}
+
+// K-ranges so that tiles x ranges fill the 256 CUs evenly; a function of the shape only (results do not depend on
+// the machine's state).  Cost model in units of one full-K tile: rounds / nsplit for the product, plus the slab
+// traffic of the reduction priced against the tile's MFMA time.
+int pick_nsplit(int M, int N, int K) {
+  const long tiles = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  const int nk = (K + TK - 1) / TK;
+  const double tile_s = 2.0 * TM * TN * (double)K / (2.5e15 / 256 * 0.5);       // one tile at half of the MFMA peak
+  double best = 1e30;
+  int best_ns = 1;
+  for (int ns = 1; ns <= 8; ns++) {
+    if (ns > 1 && nk / ns < 8) break;
+    const double rounds = (double)((tiles * ns + 255) / 256) / ns;
+    double cost = rounds * tile_s;
+    if (ns > 1) cost += (double)(ns + 2) * M * N * 4.0 / 4.0e12 + 4e-6;
+    if (cost < best * 0.97) {
+      best = cost;
+      best_ns = ns;
+    }
+  }
+  return best_ns;
+}
+
+template <bool AC, bool BC>
+int launch(const WgArgs& g, hipStream_t st) {
+  static uint64_t done_d = 0, done_s = 0;
+  const int total = g.tiles_m * g.tiles_n * g.nsplit;
+  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+  if (g.nsplit == 1) {
+    int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, true>, 2 * STAGE_BYTES, &done_d);
+    if (rc) return rc;
+    hipLaunchKernelGGL((wgemm_kernel<AC, BC, true>), dim3(grid), dim3(256), 2 * STAGE_BYTES, st, g);
+  } else {
+    int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, false>, 2 * STAGE_BYTES, &done_s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((wgemm_kernel<AC, BC, false>), dim3(grid), dim3(256), 2 * STAGE_BYTES, st, g);
+  }
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+}  // namespace
+
+extern "C" int scp_gemm_bf16_nsplit(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  return pick_nsplit(M, N, K);
+}
+
+extern "C" long scp_gemm_bf16_ws_floats(int M, int N, int K, long ldc) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int ns = pick_nsplit(M, N, K);
+  return ns > 1 ? (long)ns * M * ldc : 0;
+}
+
+extern "C" int scp_gemm_bf16(int a_col, int b_col, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                             float* C, long ldc, const float* bias, const void* mask, long ldm, float* ws, void* stream_) {
+  SCP_CHECK(M > 0 && N > 0 && K > 0, SCP_ERR_ARG, "scp_gemm_bf16: M, N, K must be positive (%d, %d, %d)", M, N, K);
+  SCP_CHECK(A && B && C, SCP_ERR_ARG, "scp_gemm_bf16: null pointer");
+  SCP_CHECK((a_col == 0 || a_col == 1) && (b_col == 0 || b_col == 1), SCP_ERR_ARG, "scp_gemm_bf16: a_col / b_col must be 0 or 1");
+  const long a_rows = a_col ? K : M, a_cols = a_col ? M : K, b_rows = b_col ? K : N, b_cols = b_col ? N : K;
+  SCP_CHECK(lda >= ((a_cols + 7) & ~7L) && ldb >= ((b_cols + 7) & ~7L) && ldc >= N, SCP_ERR_ARG,
+            "scp_gemm_bf16: leading dimension too small (operands are padded to a multiple of 8 columns)");
+  SCP_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, SCP_ERR_ARG,
+            "scp_gemm_bf16: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  SCP_CHECK(a_rows * lda * 2 < (1L << 31) && b_rows * ldb * 2 < (1L << 31), SCP_ERR_SHAPE,
+            "scp_gemm_bf16: an operand of 2 GiB or more is not supported");
+  SCP_CHECK(!mask || ldm >= N, SCP_ERR_ARG, "scp_gemm_bf16: mask leading dimension too small");
+  WgArgs g;
+  g.A = (const __bf16*)A;
+  g.B = (const __bf16*)B;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = ldc;
+  g.ldm = ldm;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.tiles_m = (M + TM - 1) / TM;
+  g.tiles_n = (N + TN - 1) / TN;
+  g.nsplit = pick_nsplit(M, N, K);
+  const int nk = (K + TK - 1) / TK;
+  g.ksteps_per_split = (nk + g.nsplit - 1) / g.nsplit;
+  g.a_bytes = (unsigned)(a_rows * lda * 2);
+  g.b_bytes = (unsigned)(b_rows * ldb * 2);
+  SCP_CHECK((long)g.tiles_m * g.tiles_n * g.nsplit < (1L << 30), SCP_ERR_SHAPE, "scp_gemm_bf16: too many tiles");
+  hipStream_t st = (hipStream_t)stream_;
+  if (g.nsplit == 1) {
+    g.C = C;
+    g.bias = bias;
+    g.mask = (const __bf16*)mask;
+  } else {
+    SCP_CHECK(ws, SCP_ERR_ARG, "scp_gemm_bf16: this shape runs as %d K-ranges and needs the workspace of scp_gemm_bf16_ws_floats",
+              g.nsplit);
+    g.C = ws;
+    g.bias = nullptr;
+    g.mask = nullptr;
+  }
+  int rc = a_col ? (b_col ? launch<true, true>(g, st) : launch<true, false>(g, st))
+                 : (b_col ? launch<false, true>(g, st) : launch<false, false>(g, st));
+  if (rc) return rc;
+  if (g.nsplit > 1) {
+    const long n = (long)M * ((N + 3) / 4);
+    hipLaunchKernelGGL(wgemm_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, g.nsplit, M, N, ldc, bias,
+                       (const __bf16*)mask, ldm, C);
+    SCP_LAUNCH_CHECK();
+  }
+  return SCP_OK;
+}

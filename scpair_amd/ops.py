@@ -207,6 +207,16 @@ def gemm_lib(ta, tb, m, n, k, A, lda, B, ldb, C, ldc):
                                             _lib.stream()), "scp_gemm_lib_bf16")
 
 
+def gemm_bf16(a_col, b_col, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldm=0):
+    """C[m][n] = sum_k A(m,k) B(n,k) (+ bias[n]) (zero where mask <= 0) on the hand-written wide MFMA kernel
+    (csrc/wgemm.hip); A / B bf16, stored [rows][ld] (col flag 0) or [K][ld] (col flag 1); C fp32 [M][ldc]."""
+    L = _lib.lib()
+    nws = L.scp_gemm_bf16_ws_floats(M, N, K, ldc)
+    ws = torch.empty((nws,), dtype=torch.float32, device=C.device) if nws else None
+    _lib.check(L.scp_gemm_bf16(a_col, b_col, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc,
+                               _lib.ptr(bias), _lib.ptr(mask), ldm, _lib.ptr(ws), _lib.stream()), "scp_gemm_bf16")
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b):
