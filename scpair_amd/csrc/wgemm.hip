@@ -11,7 +11,7 @@
 // 32x32x16 bf16 MFMA (256 accumulator registers; one wave per SIMD, 512 registers per lane).  Operand tiles go
 // global -> registers (16-byte buffer loads, the range check supplies the zeros of ragged edges) -> LDS, two LDS
 // stages of 64 KB, one barrier per K-step: the next step's global loads are in flight while this step's 64 MFMAs run.
-//   row image  [256][64]  : 128-byte rows, 16-byte chunk c of row r at chunk c ^ (r & 7); read with ds_read_b128
+//   row image  [256][64]  : 128-byte rows, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7); read with ds_read_b128
 //   col image  [64][256]  : 512-byte rows, 64-byte segment s of row k at segment s ^ (k & 3); read with the
 //                           transposing ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16 lanes), conflict-free
 // Work split: tiles x nsplit K-ranges so that the launch fills the 256 CUs evenly (1024 x 20 k is 316 tiles = 1.23
@@ -19,6 +19,7 @@
 // adds in a fixed order, together with bias and mask (bitwise reproducible: no atomics).  Consecutive workgroup ids
 // go round-robin over the 8 XCDs, so the id is remapped to give each XCD a contiguous run of tiles (the tiles that
 // share a B tile sit next to each other in one L2).
+#include <stdlib.h>
 #include "common.h"
 #include "scpair_hip.h"
 
@@ -37,6 +38,8 @@ struct WgArgs {
   int M, N, K;
   int tiles_m, tiles_n, nsplit, ksteps_per_split;
   unsigned a_bytes, b_bytes;
+  unsigned c_bytes, m_bytes;   // extent of C (one slab) and of the mask when both are below 2 GiB, else 0 (guarded global stores)
+  unsigned dbg_oor;    // experiments only (SCPAIR_WGEMM_DBG=1): every load in the K loop out of range -> no memory traffic
 };
 
 typedef __attribute__((ext_vector_type(4))) short short4_;
@@ -47,7 +50,9 @@ __device__ __forceinline__ u32x4 ld128(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 }
 
 // LDS byte offsets inside an operand image
-__device__ __forceinline__ int row_off(int r, int ch) { return r * 128 + ((ch ^ (r & 7)) << 4); }
+// (rows r and r + 1 lie in the two halves of a 256-byte bank row, so the swizzle runs over r >> 1: the 16 lanes that
+// a ds_read_b128 serves together then touch 16 distinct 16-byte slots)
+__device__ __forceinline__ int row_off(int r, int ch) { return r * 128 + ((ch ^ ((r >> 1) & 7)) << 4); }
 __device__ __forceinline__ int col_off(int k, int m) { return k * 512 + ((((m >> 5) ^ (k & 3))) << 6) + ((m & 31) << 1); }
 
 template <bool COL>
@@ -102,28 +107,38 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
   const unsigned stepA = (unsigned)((A_COL ? 8 : 32) * g.lda * 2), stepB = (unsigned)((B_COL ? 8 : 32) * g.ldb * 2);
   const int ldsA0 = A_COL ? col_off(rA, 8 * cA) : row_off(rA, cA);
   const int ldsB0 = B_COL ? col_off(rB, 8 * cB) : row_off(rB, cB);
-  const bool colokA = !A_COL || (m0 + 8 * cA < g.lda), colokB = !B_COL || (n0 + 8 * cB < g.ldb);
+  // Ragged edges come from the buffer's range check: a row image's rows >= M and a col image's k rows >= K start at
+  // or beyond the operand's last byte and load as zeros.  Only the k tail of a row image needs a test (it would run
+  // into the next row): those chunks get the top offset bit.  A col image's columns beyond ld wrap into the next k
+  // row; they only feed output rows >= M, which are not stored.
+  unsigned offA[8], offB[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    offA[i] = baseA + stepA * i;
+    offB[i] = baseB + stepB * i;
+  }
 
-  u32x4 ra[8], rb[8];
-  auto load_tiles = [&](int kt) {
+  // two register sets: the loads of K-step kt + 2 are issued during step kt and stored to LDS during step kt + 1,
+  // so a load has more than a whole K-step (64 MFMAs) to arrive
+  u32x4 ra[2][8], rb[2][8];
+  auto load_tiles = [&](int kt, int set) {       // kt >= kt1: out of range, zeros
     const int k0 = kt * TK;
-    const unsigned kA = A_COL ? (unsigned)((long)k0 * g.lda * 2) : (unsigned)k0 * 2u;
-    const unsigned kB = B_COL ? (unsigned)((long)k0 * g.ldb * 2) : (unsigned)k0 * 2u;
+    const unsigned dead = (kt < kt1 ? 0u : OOR) | g.dbg_oor;
+    const unsigned kA = (A_COL ? (unsigned)((long)k0 * g.lda * 2) : ((k0 + 8 * cA < Kp) ? (unsigned)k0 * 2u : OOR)) | dead;
+    const unsigned kB = (B_COL ? (unsigned)((long)k0 * g.ldb * 2) : ((k0 + 8 * cB < Kp) ? (unsigned)k0 * 2u : OOR)) | dead;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const bool va = A_COL ? (colokA && k0 + rA + 8 * i < g.K) : (m0 + rA + 32 * i < g.M && k0 + 8 * cA < Kp);
-      const bool vb = B_COL ? (colokB && k0 + rB + 8 * i < g.K) : (n0 + rB + 32 * i < g.N && k0 + 8 * cB < Kp);
-      ra[i] = ld128(rsA, va ? baseA + kA + stepA * i : OOR);
-      rb[i] = ld128(rsB, vb ? baseB + kB + stepB * i : OOR);
+      ra[set][i] = ld128(rsA, offA[i] + kA);
+      rb[set][i] = ld128(rsB, offB[i] + kB);
     }
   };
-  auto store_tiles = [&](int stage) {
+  auto store_tiles = [&](int stage, int set) {
     unsigned char* ia = smem + stage * STAGE_BYTES;
     unsigned char* ib = ia + TM * TK * 2;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      *(u32x4*)(ia + ldsA0 + 4096 * i) = ra[i];
-      *(u32x4*)(ib + ldsB0 + 4096 * i) = rb[i];
+      *(u32x4*)(ia + ldsA0 + 4096 * i) = ra[set][i];
+      *(u32x4*)(ib + ldsB0 + 4096 * i) = rb[set][i];
     }
   };
 
@@ -135,35 +150,139 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  if (kt0 < kt1) {
-    load_tiles(kt0);
-    store_tiles(0);
-  }
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; kt++) {
-    const int stage = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
-    if (more) load_tiles(kt + 1);
+  bf16x8 fa[2][4], fb[2][4];
+  auto read_frags = [&](int stage, int s, int set) {
     const unsigned char* ia = smem + stage * STAGE_BYTES;
     const unsigned char* ib = ia + TM * TK * 2;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      bf16x8 a[4], b[4];
+    for (int i = 0; i < 4; i++) fa[set][i] = read_frag<A_COL>(ia, wm * 128 + 32 * i, s, lane);
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = read_frag<A_COL>(ia, wm * 128 + 32 * i, s, lane);
+    for (int j = 0; j < 4; j++) fb[set][j] = read_frag<B_COL>(ib, wn * 128 + 32 * j, s, lane);
+  };
+  auto products = [&](int set) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = read_frag<B_COL>(ib, wn * 128 + 32 * j, s, lane);
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma32(fa[set][i], fb[set][j], acc[i][j]);
+  };
+  // instruction classes of __builtin_amdgcn_sched_group_barrier
+  constexpr int MFMA = 0x008, VMEM_RD = 0x020, DS_RD = 0x100, DS_WR = 0x200;
+  constexpr int RD_A = A_COL ? 2 : 1, RD_B = B_COL ? 2 : 1;     // LDS reads per fragment
+
+  load_tiles(kt0, 0);
+  store_tiles(0, 0);
+  load_tiles(kt0 + 1, 1);
+  __syncthreads();
+  // One K-step = four MFMA groups of 16 products.  The fragments of group s + 1 are read while group s multiplies,
+  // the 16 global loads of step kt + 2 are spread over group 0 and the 16 LDS stores of step kt + 1's tiles over
+  // group 3 (the other stage: nobody reads it before the barrier), so the matrix pipe always has the next group's
+  // operands in registers.  Two steps per trip (static register sets); an odd range runs one step on zero tiles.
+  auto k_step = [&](int kt, int stage, int set_ld, int set_st) {
+    read_frags(stage, 0, 0);
+    load_tiles(kt + 2, set_ld);
+    read_frags(stage, 1, 1);
+    products(0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    for (int t = 0; t < 4; t++) {
+      __builtin_amdgcn_sched_group_barrier(VMEM_RD, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_A, 0);
+      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
     }
-    if (more) store_tiles(stage ^ 1);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      __builtin_amdgcn_sched_group_barrier(VMEM_RD, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_B, 0);
+      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(stage, 2, 0);
+    products(1);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_A, 0);
+      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_B, 0);
+      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(stage, 3, 1);
+    products(0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_A, 0);
+      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_B, 0);
+      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_tiles(stage ^ 1, set_st);
+    products(1);
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      __builtin_amdgcn_sched_group_barrier(DS_WR, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
+    }
     __syncthreads();
+  };
+  for (int kt = kt0; kt < kt1; kt += 2) {
+    k_step(kt, 0, 0, 1);
+    k_step(kt + 1, 1, 1, 0);
   }
 
   // epilogue: accumulator element e of lane l is row acc_row(e, l), column l & 31 of its 32 x 32 tile
   float* Cz = g.C + (DIRECT ? 0 : (long)z * g.M * g.ldc);
+  if (m0 + TM <= g.M && n0 + TN <= g.N && !(DIRECT && g.mask)) {
+    // interior tile: no tests; one store instruction writes two 128-byte row segments
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n0 + wn * 128 + 32 * j + (lane & 31);
+      const float bn = (DIRECT && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float* p = Cz + (long)(m0 + wm * 128 + 32 * i + 4 * (lane >> 5)) * g.ldc + n;
+#pragma unroll
+        for (int e = 0; e < 16; e++) p[(long)((e & 3) + 8 * (e >> 2)) * g.ldc] = acc[i][j][e] + bn;
+      }
+    }
+    return;
+  }
+  if (g.c_bytes) {
+    // edge tile or masked output, C (and mask) below 2 GiB: buffer stores, no branches.  Rows >= M start at or beyond
+    // the buffer's last byte, so the range check drops them; columns >= N get the top offset bit.
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)Cz, 0, (int)g.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsM =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(DIRECT && g.mask ? g.mask : g.A), 0, (int)g.m_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n0 + wn * 128 + 32 * j + (lane & 31);
+      const unsigned colbad = n < g.N ? 0u : OOR;
+      const float bn = (DIRECT && g.bias && n < g.N) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int mb = m0 + wm * 128 + 32 * i + 4 * (lane >> 5);
+        const unsigned cbase = (unsigned)(((long)mb * g.ldc + n) * 4) | colbad;
+        const unsigned mbase = (unsigned)(((long)mb * g.ldm + n) * 2) | colbad;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int r = (e & 3) + 8 * (e >> 2);
+          float v = acc[i][j][e] + bn;
+          if (DIRECT && g.mask) {
+            const unsigned short mk = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsM, (int)(mbase + (unsigned)(r * g.ldm * 2)), 0, 0);
+            const float mf = __uint_as_float((unsigned)mk << 16);
+            if (!(mf > 0.f)) v = 0.f;
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, (int)(cbase + (unsigned)(r * g.ldc * 4)), 0, 0);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int n = n0 + wn * 128 + 32 * j + (lane & 31);
@@ -218,12 +337,16 @@ __global__ __launch_bounds__(256) void wgemm_reduce_kernel(const float* __restri
 // the machine's state).  Cost model in units of one full-K tile: rounds / nsplit for the product, plus the slab
 // traffic of the reduction priced against the tile's MFMA time.
 int pick_nsplit(int M, int N, int K) {
+  if (const char* e = getenv("SCPAIR_WGEMM_NSPLIT")) {      // experiments only
+    const int v = atoi(e);
+    if (v >= 1 && v <= 16 && v <= (K + TK - 1) / TK) return v;
+  }
   const long tiles = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
   const int nk = (K + TK - 1) / TK;
   const double tile_s = 2.0 * TM * TN * (double)K / (2.5e15 / 256 * 0.5);       // one tile at half of the MFMA peak
   double best = 1e30;
   int best_ns = 1;
-  for (int ns = 1; ns <= 8; ns++) {
+  for (int ns = 1; ns <= 16; ns++) {
     if (ns > 1 && nk / ns < 8) break;
     const double rounds = (double)((tiles * ns + 255) / 256) / ns;
     double cost = rounds * tile_s;
@@ -297,7 +420,14 @@ extern "C" int scp_gemm_bf16(int a_col, int b_col, int M, int N, int K, const vo
   g.ksteps_per_split = (nk + g.nsplit - 1) / g.nsplit;
   g.a_bytes = (unsigned)(a_rows * lda * 2);
   g.b_bytes = (unsigned)(b_rows * ldb * 2);
+  g.dbg_oor = (getenv("SCPAIR_WGEMM_DBG") && atoi(getenv("SCPAIR_WGEMM_DBG")) == 1) ? 0x80000000u : 0u;
   SCP_CHECK((long)g.tiles_m * g.tiles_n * g.nsplit < (1L << 30), SCP_ERR_SHAPE, "scp_gemm_bf16: too many tiles");
+  {
+    const long cb = (long)M * ldc * 4, mb = mask ? (long)M * ldm * 2 : 2;
+    const bool small = cb < (1L << 31) && mb < (1L << 31);
+    g.c_bytes = small ? (unsigned)cb : 0u;
+    g.m_bytes = small ? (unsigned)mb : 0u;
+  }
   hipStream_t st = (hipStream_t)stream_;
   if (g.nsplit == 1) {
     g.C = C;
