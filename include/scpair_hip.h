@@ -56,6 +56,8 @@ int scp_spmm_dw(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t
  * [N][ldw] (ldw % 8 == 0, zero padded; kept current by scp_adamw_multi / scp_cast_bf16) and dY comes transposed
  * as bf16 [N][ldt] (scp_transpose_bf16) */
 int scp_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
+/* dst = bf16(relu(src)): the input of the ZINB zero-inflation layer pi = Linear(relu(z)) (model.py:240,255-256) */
+int scp_relu_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
 int scp_transpose_bf16(const float* src, int rows, int cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
 int scp_spmm_fwd_bf16_min_split(int F);   /* smallest nsplit scp_spmm_fwd_bf16 accepts for F features */
 /* t_pk: the packed entries of scp_tiles_build; required when t_val is given (the kernels read them instead of key / val) */

@@ -861,13 +861,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 // ------------------------------------------------------------------------------------------------------
 // helpers: fp32 -> bf16 cast into a padded shadow, and fp32 [rows][cols] -> bf16 transposed [cols][ldt]
 // ------------------------------------------------------------------------------------------------------
+template <bool RELU>
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, long rows, long cols, long lds_,
                                                         __bf16* __restrict__ dst, long ldd) {
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   long n = rows * ldd;
   if (i >= n) return;
   long rr = i / ldd, c = i % ldd;
-  dst[i] = (c < cols) ? (__bf16)src[rr * lds_ + c] : (__bf16)0.f;
+  float v = (c < cols) ? src[rr * lds_ + c] : 0.f;
+  if (RELU && v < 0.f) v = 0.f;                  // a NaN stays a NaN, as in torch.relu
+  dst[i] = (__bf16)v;
 }
 
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* __restrict__ src, int rows, int cols, long lds_,
@@ -888,8 +891,19 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* __rest
 extern "C" int scp_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst, long ld_dst, void* stream_) {
   SCP_CHECK(src && dst && rows > 0 && cols > 0 && ld_dst >= cols, SCP_ERR_ARG, "scp_cast_bf16: bad argument");
   long n = rows * ld_dst;
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src, rows,
-                     cols, ld_src, (__bf16*)dst, ld_dst);
+  hipLaunchKernelGGL(cast_bf16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src,
+                     rows, cols, ld_src, (__bf16*)dst, ld_dst);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+// dst = bf16(relu(src)): the input of the ZINB zero-inflation layer, pi = Linear(relu(z)) (model.py:240,255-256), cast
+// for the wide GEMM in the same pass that applies the relu
+extern "C" int scp_relu_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst, long ld_dst, void* stream_) {
+  SCP_CHECK(src && dst && rows > 0 && cols > 0 && ld_dst >= cols, SCP_ERR_ARG, "scp_relu_cast_bf16: bad argument");
+  long n = rows * ld_dst;
+  hipLaunchKernelGGL(cast_bf16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src,
+                     rows, cols, ld_src, (__bf16*)dst, ld_dst);
   SCP_LAUNCH_CHECK();
   return SCP_OK;
 }

@@ -235,7 +235,7 @@ class Output_Module_Raw(nn.Module):
         lin = self.output_mean[0]
         if likelihood == "zinb":
             # The G x G zero-inflation layer needs px_mu as a GEMM operand, so the pre-activations are materialised:
-            # z = Linear(h) (MFMA GEMM), px_mu = relu(z), pi = Linear_GxG(px_mu) (library GEMM in bf16 mode), then
+            # z = Linear(h) (MFMA GEMM), px_mu = relu(z), pi = Linear_GxG(px_mu) (hand-written wide MFMA GEMM in bf16 mode), then
             # softmax / exp / ZINB likelihood and their backward in the fused row kernels.
             if fs is not None or thp is not None or self.zero_inflated != True:  # noqa: E712
                 return None
@@ -247,7 +247,7 @@ class Output_Module_Raw(nn.Module):
                 raise Exception("The library size is missing. Please ensure that either the 'sample_factor' or "
                                 "'infer_library_size' parameter for the raw counts decoder is set to True.")
             z = ops.linear(h, lin.weight, lin.bias)
-            pi = self.output_dropout(torch.relu(z))
+            pi = self.output_dropout(z, relu_input=True)          # Linear(relu(z)), model.py:240,255-256
             return ops.raw_rows_loss(z, pi, L, labels.to_dense())
         if self.sample_factor == True:  # noqa: E712
             L, lat = lib, None

@@ -193,12 +193,14 @@ def _pick_split(M, N, K):
 _LIB_GEMM_MIN = 1 << 29      # M*N*K from which a plain nn.Linear goes to the library bf16 GEMM (precision 'bf16' only)
 
 
-def cast_bf16(x, rows, cols):
-    """bf16 copy [rows, ld] (ld = cols rounded up to 8, zero padded) of a contiguous fp32 [rows, cols] tensor."""
+def cast_bf16(x, rows, cols, relu=False):
+    """bf16 copy [rows, ld] (ld = cols rounded up to 8, zero padded) of a contiguous fp32 [rows, cols] tensor
+    (relu: of relu(x), in the same pass)."""
     ld = (cols + 7) // 8 * 8
     out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.lib().scp_cast_bf16(x.data_ptr(), rows, cols, cols, out.data_ptr(), ld, _lib.stream()),
-               "scp_cast_bf16")
+    L = _lib.lib()
+    fn, name = (L.scp_relu_cast_bf16, "scp_relu_cast_bf16") if relu else (L.scp_cast_bf16, "scp_cast_bf16")
+    _lib.check(fn(x.data_ptr(), rows, cols, cols, out.data_ptr(), ld, _lib.stream()), name)
     return out
 
 
@@ -218,8 +220,14 @@ def gemm_bf16(a_col, b_col, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=Non
 
 
 class LinearFn(torch.autograd.Function):
+    """y = [relu](x) W^T + b.  Wide layers in precision 'bf16' (the ZINB G x G zero-inflation layer model.py:228,
+    the VAE 900 <-> G layers pairedVAE.py:111-119) run forward, input gradient and weight gradient on the hand-written
+    wide MFMA kernel (scp_gemm_bf16): bf16 weight shadow (kept current by FusedAdamW) x bf16 activations, bias in the
+    forward epilogue, the relu's backward as a mask in the input-gradient epilogue.  relu_in fuses the torch.relu the
+    reference applies to the layer's input (model.py:240)."""
+
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, relu_in=False):
         _lib.require_cuda(x, W, b)
         x = _f32c(x)
         Wc = _f32c(W)
@@ -227,17 +235,17 @@ class LinearFn(torch.autograd.Function):
         N = Wc.shape[0]
         y = _empty((M, N), x)
         ctx.has_bias = b is not None
+        ctx.relu_in = bool(relu_in)
         ctx.lib = _ns() == 1 and M * N * K >= _LIB_GEMM_MIN and W.is_contiguous() and W.dtype == torch.float32
         if ctx.lib:
-            # wide plain GEMM: bf16 weight shadow (kept current by FusedAdamW) x bf16 activations, library kernel
             sh = shadow_of(W)
-            xb = cast_bf16(x, M, K)
-            gemm_lib(1, 0, N, M, K, sh, sh.shape[1], xb, xb.shape[1], y, N)
-            if b is not None:
-                slab_reduce(y, 1, M, N, y, _f32c(b))
+            xb = cast_bf16(x, M, K, relu=ctx.relu_in)
+            gemm_bf16(0, 0, M, N, K, xb, xb.shape[1], sh, sh.shape[1], y, N, bias=_f32c(b))
             ctx.save_for_backward(xb, W)
             ctx.dims = (M, N, K)
             return y
+        if ctx.relu_in:
+            x = torch.relu(x)
         gemm_nt_auto(M, N, K, x, K, 1, Wc, K, 1, y, bias=_f32c(b))
         ctx.save_for_backward(x, Wc)
         return y
@@ -253,13 +261,16 @@ class LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 sh = shadow_of(W)
                 dx = _empty((M, K), dy)
-                gemm_lib(0, 0, K, M, N, sh, sh.shape[1], dyb, dyb.shape[1], dx, K)
+                # dx[m][j] = sum_n dy[m][n] W[n][j]: W is the k-major ("col") operand; relu'(x) = [relu(x) > 0]
+                gemm_bf16(0, 1, M, K, N, dyb, dyb.shape[1], sh, sh.shape[1], dx, K,
+                          mask=xb if ctx.relu_in else None, ldm=xb.shape[1])
             if ctx.needs_input_grad[1]:
                 dW = _empty((N, K), dy)
-                gemm_lib(0, 1, K, N, M, xb, xb.shape[1], dyb, dyb.shape[1], dW, K)
+                # dW[n][j] = sum_m dy[m][n] x[m][j]: both operands k-major
+                gemm_bf16(1, 1, N, K, M, dyb, dyb.shape[1], xb, xb.shape[1], dW, K)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy, M, N)
-            return dx, dW, db
+            return dx, dW, db, None
         x, W = ctx.saved_tensors
         M, K = x.shape
         N = W.shape[0]
@@ -267,17 +278,19 @@ class LinearFn(torch.autograd.Function):
             dx = _empty((M, K), x)
             # dx[m][j] = sum_n dy[m][n] W[n][j]
             gemm_nt_auto(M, K, N, dy, N, 1, W, 1, K, dx)
+            if ctx.relu_in:
+                dx = dx * (x > 0)
         if ctx.needs_input_grad[1]:
             dW = _empty((N, K), x)
             # dW[n][j] = sum_m dy[m][n] x[m][j]
             gemm_nt_auto(N, K, M, dy, 1, N, x, 1, K, dW)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
-def linear(x, W, b=None):
-    return LinearFn.apply(x, W, b)
+def linear(x, W, b=None, relu_input=False):
+    return LinearFn.apply(x, W, b, relu_input)
 
 
 # ------------------------------------------------------------------------------------------------

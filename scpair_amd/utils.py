@@ -148,8 +148,10 @@ def FCNN(layers, layernorm=True, activation=nn.ReLU(), batchnorm=False, dropout_
 class HipLinear(nn.Linear):
     """nn.Linear whose forward is the MFMA GEMM (same parameters / init as nn.Linear)."""
 
-    def forward(self, x):
-        return ops.linear(x, self.weight, self.bias)
+    def forward(self, x, relu_input=False):
+        """relu_input: y = Linear(relu(x)) with the relu folded into the layer (its cast pass forward, a mask in the
+        input-gradient epilogue backward)."""
+        return ops.linear(x, self.weight, self.bias, relu_input)
 
 
 def init_weights(nn_modules, method="xavier_normal"):

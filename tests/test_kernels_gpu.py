@@ -447,10 +447,13 @@ def test_bf16_shadow_tracks_weights(S):
     S.ops.set_precision("fp32")
 
 
-def test_linear_library_gemm_bf16(S):
-    """Wide plain nn.Linear in bf16 mode (M*N*K >= 2^29: ZINB G x G layer, VAE 900<->G layers) runs on the library
-    bf16 GEMM behind scp_gemm_lib_bf16: forward, dgrad, wgrad and bias gradient against fp64 matmuls of the
-    bf16-rounded operands; the shadow stays equal to bf16(W) across a FusedAdamW step."""
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_linear_wide_gemm_bf16(S, relu_in):
+    """Wide plain nn.Linear in bf16 mode (M*N*K >= 2^29: ZINB G x G layer model.py:228,255-256, VAE 900<->G layers
+    pairedVAE.py:111-119) runs on the hand-written wide MFMA GEMM (scp_gemm_bf16): forward (bias in the epilogue),
+    dgrad (relu mask in the epilogue when the layer's input is relu(x), model.py:240), wgrad and bias gradient against
+    fp64 matmuls of the bf16-rounded operands (tolerance 1e-4 relative to the largest element: fp32 accumulation
+    order); the shadow stays equal to bf16(W) across a FusedAdamW step."""
     S.ops.set_precision("bf16")
     g = torch.Generator().manual_seed(5)
     M, N, K = 300, 2050, 1801                      # not multiples of 8: padded leading dimensions
@@ -459,19 +462,39 @@ def test_linear_library_gemm_bf16(S):
     W = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.05).to(S.dev))
     b = torch.nn.Parameter(torch.randn(N, generator=g).to(S.dev))
     dy = torch.randn(M, N, generator=g).to(S.dev)
-    y = S.ops.linear(x, W, b)
+    y = S.ops.linear(x, W, b, relu_input=relu_in)
     y.backward(dy)
-    xb, Wb, dyb = x.detach().bfloat16().double(), W.detach().bfloat16().double(), dy.bfloat16().double()
+    xin = torch.relu(x.detach()) if relu_in else x.detach()
+    xb, Wb, dyb = xin.bfloat16().double(), W.detach().bfloat16().double(), dy.bfloat16().double()
     sc = lambda t: 1e-4 * float(t.abs().max())
-    close(y, xb @ Wb.t() + b.detach().double(), rtol=1e-4, atol=sc(y), what="lib gemm fwd")
-    close(x.grad, dyb @ Wb, rtol=1e-4, atol=sc(x.grad), what="lib gemm dgrad")
-    close(W.grad, dyb.t() @ xb, rtol=1e-4, atol=sc(W.grad), what="lib gemm wgrad")
-    close(b.grad, dy.double().sum(0), rtol=1e-5, atol=1e-4, what="lib gemm dbias")
+    close(y, xb @ Wb.t() + b.detach().double(), rtol=1e-4, atol=sc(y), what="wide gemm fwd")
+    dx_ref = dyb @ Wb
+    if relu_in:
+        dx_ref = dx_ref * (x.detach().bfloat16() > 0).double()
+        assert bool((x.grad[x.detach() <= 0] == 0).all())
+    close(x.grad, dx_ref, rtol=1e-4, atol=sc(x.grad), what="wide gemm dgrad")
+    close(W.grad, dyb.t() @ xb, rtol=1e-4, atol=sc(W.grad), what="wide gemm wgrad")
+    close(b.grad, dy.double().sum(0), rtol=1e-5, atol=1e-4, what="wide gemm dbias")
     opt = S.ops.FusedAdamW([W, b], lr=1e-2, weight_decay=0.0)
     opt.step()
     sh = S.ops.shadow_of(W, create=False)
     assert sh is not None and torch.equal(sh[:, :K], W.detach().bfloat16())
     S.ops.set_precision("fp32")
+
+
+def test_linear_relu_input_small_shapes_equal_torch(S):
+    """relu_input on the small-shape path (hand-written split-bf16 GEMM, fp32-equivalent) against torch autograd."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(50, 70, generator=g).to(S.dev).requires_grad_(True)
+    W = torch.nn.Parameter((torch.randn(30, 70, generator=g) * 0.1).to(S.dev))
+    b = torch.nn.Parameter(torch.randn(30, generator=g).to(S.dev))
+    dy = torch.randn(50, 30, generator=g).to(S.dev)
+    S.ops.linear(x, W, b, relu_input=True).backward(dy)
+    got = [x.grad.clone(), W.grad.clone(), b.grad.clone()]
+    x.grad = W.grad = b.grad = None
+    torch.nn.functional.linear(torch.relu(x), W, b).backward(dy)
+    for a_, r_ in zip(got, [x.grad, W.grad, b.grad]):
+        close(a_, r_.double(), rtol=1e-4, atol=1e-5)
 
 
 def test_tiles_to_dense(S):
