@@ -86,7 +86,8 @@ int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const
 int scp_gemm_nt(int M, int N, int K, const float* A, long a_row_stride, long a_k_stride, const float* B,
                 long b_row_stride, long b_k_stride, float* C, long ldc, const float* bias /* [N] nullable */,
                 int accumulate, int nsplit, int ns, void* stream);
-/* wide plain GEMMs (ZINB G x G layer model.py:228, VAE 900<->G layers pairedVAE.py:111-119) in bf16 mode: rocBLAS,
+/* rocBLAS bf16 GEMM on the shapes of the wide layers (ZINB G x G model.py:228, VAE 900<->G pairedVAE.py:111-119): the
+ * comparison that benchmarks/wgemm_bench.py times beside scp_gemm_bf16 below; no product path calls it.
  * bf16 operands, fp32 accumulate/output.  Column-major BLAS convention, ta/tb: 0 = N, 1 = T; see libgemm.hip for the
  * three row-major nn.Linear cases */
 int scp_gemm_lib_bf16(int ta, int tb, int m, int n, int k, const void* A_bf16, long lda, const void* B_bf16, long ldb,

@@ -1,10 +1,6 @@
-// Large plain GEMMs of the dense layers (nn.Linear with both dimensions wide: the ZINB G x G zero-inflation layer
-// model.py:228, the VAE 900 <-> G layers pairedVAE.py:111-119) in precision mode 'bf16'.
-//
-// These are library-shaped problems with nothing to fuse, so they go to rocBLAS (bf16 inputs, fp32 accumulate and
-// output) instead of the hand-written kernels, which exist for the operations a library cannot express (sparse
-// operands densified in LDS, likelihood epilogues, split-K feeding LayerNorm).  Operands are bf16 copies: the
-// weight shadow kept current by the fused AdamW kernel, activations / gradients cast by scp_cast_bf16.
+// rocBLAS bf16 GEMM, kept as the COMPARISON for the hand-written wide GEMM (wgemm.hip, scp_gemm_bf16) that runs the
+// wide nn.Linear layers (ZINB G x G model.py:228, VAE 900 <-> G pairedVAE.py:111-119) in precision mode 'bf16':
+// benchmarks/wgemm_bench.py times both on the same operands.  No product path calls this entry point.
 #include <rocblas/rocblas.h>
 #include "common.h"
 #include "scpair_hip.h"
