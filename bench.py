@@ -166,6 +166,9 @@ def main():
         for d_ in (A, Bd):
             d_.opt.fuse_first_layer(*d_.first)
             d_.fused = True
+            wide = getattr(d_.dec, "output_dropout", None)        # C3 (--zinb): the G x G zero-inflation layer
+            if isinstance(wide, torch.nn.Linear):
+                d_.opt.fuse_weight_update(wide.weight)
 
     rng = np.random.default_rng(1234 + rank)
     state = {"perm": rng.permutation(cells_here), "cur": 0}

@@ -105,6 +105,16 @@ int scp_gemm_bf16_nsplit(int M, int N, int K);
 long scp_gemm_bf16_ws_floats(int M, int N, int K, long ldc);
 int scp_gemm_bf16(int a_col, int b_col, int M, int N, int K, const void* A_bf16, long lda, const void* B_bf16, long ldb,
                   float* C, long ldc, const float* bias, const void* mask_bf16, long ldm, float* ws, void* stream);
+/* Weight gradient of a wide nn.Linear, dW[n][j] = sum_m dy[m][n] x[m][j] (A = dy stored [K][lda], B = x stored [K][ldb],
+ * both "col" operands of scp_gemm_bf16; here M = out features, N = in features, K = batch), with the AdamW step of that
+ * weight (torch.optim.AdamW semantics as in scp_adamw_multi; reference utils.py:160-176 optimizer.step()) applied in the
+ * kernel's epilogue: W [M][ldw] fp32 master weights, exp_avg / exp_avg_sq (same layout) and the bf16 shadow are updated
+ * in place and the gradient never reaches HBM.  Single-process training only.  Needs N % 4 == 0, ldw % 4 == 0,
+ * ld_bf16 % 4 == 0 and 16-byte aligned W / moments (SCP_ERR_SHAPE otherwise: use scp_gemm_bf16 + scp_adamw_multi). */
+int scp_gemm_bf16_adamw(int M, int N, int K, const void* A_bf16, long lda, const void* B_bf16, long ldb, float* W, long ldw,
+                        float* exp_avg, float* exp_avg_sq, void* W_bf16, long ld_bf16, float lr, float weight_decay,
+                        float beta1, float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale,
+                        const float* bc_dev /* nullable */, void* stream);
 int scp_slab_reduce(const float* slabs, long slab_stride, int nslab, int rows, int cols, long ld,
                     const float* bias, float* out, long ldo, void* stream);
 int scp_colsum(const float* X, long ld, int rows, int cols, float* out, float* partials_ws /* [32*cols] */,

@@ -65,6 +65,7 @@ _SIGS = {
     "scp_gemm_bf16_nsplit": (I, [I, I, I]),
     "scp_gemm_bf16_ws_floats": (L, [I, I, I, L]),
     "scp_gemm_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, L, P, P]),
+    "scp_gemm_bf16_adamw": (I, [I, I, I, P, L, P, L, P, L, P, P, P, L, F, F, F, F, F, F, F, F, P, P]),
     "scp_slab_reduce": (I, [P, L, I, I, I, L, P, P, L, P]),
     "scp_colsum": (I, [P, L, I, I, P, P, P]),
     "scp_colsum_noalloc_max_cols": (I, []),

@@ -39,6 +39,10 @@ struct WgArgs {
   int tiles_m, tiles_n, nsplit, ksteps_per_split;
   unsigned a_bytes, b_bytes;
   unsigned c_bytes, m_bytes;   // extent of C (one slab) and of the mask when both are below 2 GiB, else 0 (guarded global stores)
+  // weight gradient with the AdamW step applied in the epilogue (EPI_ADAMW): C = fp32 master weights, updated in place
+  float* adam_m; float* adam_v; __bf16* adam_sh; long adam_ldsh;
+  float lr, wd, b1, b2, eps, bc1, bc2, gscale;
+  const float* bc_dev;       // optional device words {bias_corr1, bias_corr2} (HIP-graph replays), else bc1 / bc2
   unsigned dbg_oor;    // experiments only (SCPAIR_WGEMM_DBG=1): every load in the K loop out of range -> no memory traffic
 };
 
@@ -74,8 +78,11 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* img, int r0, in
   }
 }
 
-template <bool A_COL, bool B_COL, bool DIRECT>
+enum { EPI_SLAB = 0, EPI_DIRECT = 1, EPI_ADAMW = 2 };
+
+template <bool A_COL, bool B_COL, int EPI>
 __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
+  constexpr bool DIRECT = EPI == EPI_DIRECT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -236,6 +243,90 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
   }
 
   // epilogue: accumulator element e of lane l is row acc_row(e, l), column l & 31 of its 32 x 32 tile
+  if (EPI == EPI_ADAMW) {
+    // The tile is a block of the weight gradient: apply torch.optim.AdamW's update to the master weights, the moments
+    // and the bf16 shadow right here; the gradient never reaches HBM.  Every wave passes its 32-row strips through a
+    // private LDS buffer [32][132] (the operand stages are free after the loop's last barrier; same-wave LDS accesses
+    // need no barrier) and walks them row-wise: half a wave per 512-byte row segment, float4 loads and stores.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float* wt = (float*)smem + wave * (32 * 132);
+    const float bc1 = g.bc_dev ? g.bc_dev[0] : g.bc1, bc2 = g.bc_dev ? g.bc_dev[1] : g.bc2;
+    const AdamHyper hy = adam_hyper(g.lr, g.wd, g.b1, g.b2, g.eps, bc1, bc2, g.gscale);
+    const int c4 = (lane & 31) * 4;
+    const int n = n0 + wn * 128 + c4;
+    const bool col_ok = n + 4 <= g.N;             // N % 4 == 0 (host-checked): a float4 is all in or all out
+    const bool interior = m0 + TM <= g.M && n0 + TN <= g.N;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) wt[acc_row(e, lane) * 132 + 32 * j + (lane & 31)] = acc[i][j][e];
+      __builtin_amdgcn_wave_barrier();
+      const int mrow = m0 + wm * 128 + 32 * i + (lane >> 5);
+      if (interior) {
+        // no tests: the loads of four row pairs are issued before the first update, twelve float4 in flight per lane
+#pragma unroll
+        for (int it0 = 0; it0 < 16; it0 += 4) {
+          f4 pv[4], mv[4], vv[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const long idx = (long)(mrow + 2 * (it0 + u)) * g.ldc + n;
+            pv[u] = *(const f4*)(g.C + idx);
+            mv[u] = *(const f4*)(g.adam_m + idx);
+            vv[u] = *(const f4*)(g.adam_v + idx);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int row = 2 * (it0 + u) + (lane >> 5);
+            const f4 gv = *(const f4*)(wt + row * 132 + c4);
+            const long idx = (long)(mrow + 2 * (it0 + u)) * g.ldc + n;
+            bf16x4 sh4;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              float p_ = pv[u][t], m_ = mv[u][t], v_ = vv[u][t];
+              adamw_update_fast(hy, p_, gv[t], m_, v_);
+              pv[u][t] = p_;
+              mv[u][t] = m_;
+              vv[u][t] = v_;
+              sh4[t] = (__bf16)p_;
+            }
+            *(f4*)(g.C + idx) = pv[u];
+            *(f4*)(g.adam_m + idx) = mv[u];
+            *(f4*)(g.adam_v + idx) = vv[u];
+            *(bf16x4*)(g.adam_sh + (long)(mrow + 2 * (it0 + u)) * g.adam_ldsh + n) = sh4;
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int it = 0; it < 16; it++) {
+          const int row = 2 * it + (lane >> 5);
+          const f4 gv = *(const f4*)(wt + row * 132 + c4);
+          const int m = m0 + wm * 128 + 32 * i + row;
+          if (col_ok && m < g.M) {
+            const long idx = (long)m * g.ldc + n;
+            f4 pv = *(const f4*)(g.C + idx), mv = *(const f4*)(g.adam_m + idx), vv = *(const f4*)(g.adam_v + idx);
+            bf16x4 sh4;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              float p_ = pv[t], m_ = mv[t], v_ = vv[t];
+              adamw_update_fast(hy, p_, gv[t], m_, v_);
+              pv[t] = p_;
+              mv[t] = m_;
+              vv[t] = v_;
+              sh4[t] = (__bf16)p_;
+            }
+            *(f4*)(g.C + idx) = pv;
+            *(f4*)(g.adam_m + idx) = mv;
+            *(f4*)(g.adam_v + idx) = vv;
+            *(bf16x4*)(g.adam_sh + (long)m * g.adam_ldsh + n) = sh4;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   float* Cz = g.C + (DIRECT ? 0 : (long)z * g.M * g.ldc);
   if (m0 + TM <= g.M && n0 + TN <= g.N && !(DIRECT && g.mask)) {
     // interior tile: no tests; one store instruction writes two 128-byte row segments
@@ -365,13 +456,13 @@ int launch(const WgArgs& g, hipStream_t st) {
   const int total = g.tiles_m * g.tiles_n * g.nsplit;
   const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
   if (g.nsplit == 1) {
-    int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, true>, 2 * STAGE_BYTES, &done_d);
+    int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, EPI_DIRECT>, 2 * STAGE_BYTES, &done_d);
     if (rc) return rc;
-    hipLaunchKernelGGL((wgemm_kernel<AC, BC, true>), dim3(grid), dim3(256), 2 * STAGE_BYTES, st, g);
+    hipLaunchKernelGGL((wgemm_kernel<AC, BC, EPI_DIRECT>), dim3(grid), dim3(256), 2 * STAGE_BYTES, st, g);
   } else {
-    int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, false>, 2 * STAGE_BYTES, &done_s);
+    int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, EPI_SLAB>, 2 * STAGE_BYTES, &done_s);
     if (rc) return rc;
-    hipLaunchKernelGGL((wgemm_kernel<AC, BC, false>), dim3(grid), dim3(256), 2 * STAGE_BYTES, st, g);
+    hipLaunchKernelGGL((wgemm_kernel<AC, BC, EPI_SLAB>), dim3(grid), dim3(256), 2 * STAGE_BYTES, st, g);
   }
   SCP_LAUNCH_CHECK();
   return SCP_OK;
@@ -390,6 +481,53 @@ extern "C" long scp_gemm_bf16_ws_floats(int M, int N, int K, long ldc) {
   return ns > 1 ? (long)ns * M * ldc : 0;
 }
 
+// dW = A^T-style product of two k-major operands with the AdamW step of W in the epilogue (see the header)
+extern "C" int scp_gemm_bf16_adamw(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* W, long ldw,
+                                   float* exp_avg, float* exp_avg_sq, void* W_bf16, long ld_bf16, float lr, float weight_decay,
+                                   float beta1, float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale,
+                                   const float* bc_dev, void* stream_) {
+  SCP_CHECK(M > 0 && N > 0 && K > 0, SCP_ERR_ARG, "scp_gemm_bf16_adamw: M, N, K must be positive (%d, %d, %d)", M, N, K);
+  SCP_CHECK(A && B && W && exp_avg && exp_avg_sq && W_bf16, SCP_ERR_ARG, "scp_gemm_bf16_adamw: null pointer");
+  SCP_CHECK(lda >= ((M + 7) & ~7L) && ldb >= ((N + 7) & ~7L) && ldw >= N && ld_bf16 >= N, SCP_ERR_ARG,
+            "scp_gemm_bf16_adamw: leading dimension too small");
+  SCP_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, SCP_ERR_ARG,
+            "scp_gemm_bf16_adamw: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  SCP_CHECK((long)K * lda * 2 < (1L << 31) && (long)K * ldb * 2 < (1L << 31), SCP_ERR_SHAPE,
+            "scp_gemm_bf16_adamw: an operand of 2 GiB or more is not supported");
+  SCP_CHECK(N % 4 == 0 && ldw % 4 == 0 && ld_bf16 % 4 == 0 &&
+                (((uintptr_t)W | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) == 0 && ((uintptr_t)W_bf16 % 8) == 0,
+            SCP_ERR_SHAPE, "scp_gemm_bf16_adamw: needs N %% 4 == 0, leading dimensions %% 4 == 0 and 16-byte aligned W / moments");
+  SCP_CHECK(bc_dev || (bias_corr1 > 0.f && bias_corr2 > 0.f), SCP_ERR_ARG, "scp_gemm_bf16_adamw: bias corrections must be > 0");
+  WgArgs g = {};
+  g.A = (const __bf16*)A;
+  g.B = (const __bf16*)B;
+  g.C = W;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = ldw;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.tiles_m = (M + TM - 1) / TM;
+  g.tiles_n = (N + TN - 1) / TN;
+  g.nsplit = 1;                                   // the update needs the complete sum: one K-range
+  g.ksteps_per_split = (K + TK - 1) / TK;
+  g.a_bytes = (unsigned)((long)K * lda * 2);
+  g.b_bytes = (unsigned)((long)K * ldb * 2);
+  g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_sh = (__bf16*)W_bf16; g.adam_ldsh = ld_bf16;
+  g.lr = lr; g.wd = weight_decay; g.b1 = beta1; g.b2 = beta2; g.eps = eps; g.bc1 = bias_corr1; g.bc2 = bias_corr2;
+  g.gscale = grad_scale; g.bc_dev = bc_dev;
+  SCP_CHECK((long)g.tiles_m * g.tiles_n < (1L << 30), SCP_ERR_SHAPE, "scp_gemm_bf16_adamw: too many tiles");
+  static uint64_t done_a = 0;
+  int rc = scp_set_smem((const void*)wgemm_kernel<true, true, EPI_ADAMW>, 2 * STAGE_BYTES, &done_a);
+  if (rc) return rc;
+  const int total = g.tiles_m * g.tiles_n;
+  hipLaunchKernelGGL((wgemm_kernel<true, true, EPI_ADAMW>), dim3((unsigned)(((total + 7) / 8) * 8)), dim3(256), 2 * STAGE_BYTES,
+                     (hipStream_t)stream_, g);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
 extern "C" int scp_gemm_bf16(int a_col, int b_col, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                              float* C, long ldc, const float* bias, const void* mask, long ldm, float* ws, void* stream_) {
   SCP_CHECK(M > 0 && N > 0 && K > 0, SCP_ERR_ARG, "scp_gemm_bf16: M, N, K must be positive (%d, %d, %d)", M, N, K);
@@ -403,7 +541,7 @@ extern "C" int scp_gemm_bf16(int a_col, int b_col, int M, int N, int K, const vo
   SCP_CHECK(a_rows * lda * 2 < (1L << 31) && b_rows * ldb * 2 < (1L << 31), SCP_ERR_SHAPE,
             "scp_gemm_bf16: an operand of 2 GiB or more is not supported");
   SCP_CHECK(!mask || ldm >= N, SCP_ERR_ARG, "scp_gemm_bf16: mask leading dimension too small");
-  WgArgs g;
+  WgArgs g = {};
   g.A = (const __bf16*)A;
   g.B = (const __bf16*)B;
   g.lda = lda;

@@ -803,6 +803,12 @@ class scPair_object():
                   {'params': nodecay_d, 'weight_decay': 0, 'lr': lr}]
         opt = ops.FusedAdamW([g for g in groups if len(g['params']) > 0])
         self._wire_first_layers(opt, encoder, ('hidden_rep', 'hidden_lib'))
+        if self.grad_sync is None and self.fuse_optimizer:
+            # the ZINB head's G x G zero-inflation layer (model.py:228): AdamW step inside its weight-gradient GEMM
+            # when the layer runs on the wide bf16 kernel (other precisions / small G keep the two-kernel path)
+            wide = getattr(decoder, 'output_dropout', None)
+            if isinstance(wide, nn.Linear) and wide.weight.requires_grad:
+                opt.fuse_weight_update(wide.weight)
         return opt
 
     def _wire_first_layers(self, opt, encoder, names):

@@ -227,7 +227,7 @@ class LinearFn(torch.autograd.Function):
     reference applies to the layer's input (model.py:240)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu_in=False):
+    def forward(ctx, x, W, b, relu_in=False, fused=None):
         _lib.require_cuda(x, W, b)
         x = _f32c(x)
         Wc = _f32c(W)
@@ -237,6 +237,8 @@ class LinearFn(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.relu_in = bool(relu_in)
         ctx.lib = _ns() == 1 and M * N * K >= _LIB_GEMM_MIN and W.is_contiguous() and W.dtype == torch.float32
+        # AdamW step inside the weight-gradient kernel (FusedAdamW.fuse_weight_update): wide path only, float4 epilogue
+        ctx.fused = fused if (ctx.lib and K % 4 == 0) else None
         if ctx.lib:
             sh = shadow_of(W)
             xb = cast_bf16(x, M, K, relu=ctx.relu_in)
@@ -264,13 +266,20 @@ class LinearFn(torch.autograd.Function):
                 # dx[m][j] = sum_n dy[m][n] W[n][j]: W is the k-major ("col") operand; relu'(x) = [relu(x) > 0]
                 gemm_bf16(0, 1, M, K, N, dyb, dyb.shape[1], sh, sh.shape[1], dx, K,
                           mask=xb if ctx.relu_in else None, ldm=xb.shape[1])
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and ctx.fused is not None:
+                # weight gradient + AdamW step of W in one kernel (after dx, which reads the shadow this rewrites):
+                # dW never reaches HBM, autograd gets no gradient for W
+                m_, v_, sh_, hp = ctx.fused.begin_step(W)
+                _lib.check(_lib.lib().scp_gemm_bf16_adamw(N, K, M, dyb.data_ptr(), dyb.shape[1], xb.data_ptr(), xb.shape[1],
+                                                          W.data_ptr(), K, m_.data_ptr(), v_.data_ptr(), sh_.data_ptr(),
+                                                          sh_.shape[1], *hp, _lib.stream()), "scp_gemm_bf16_adamw")
+            elif ctx.needs_input_grad[1]:
                 dW = _empty((N, K), dy)
                 # dW[n][j] = sum_m dy[m][n] x[m][j]: both operands k-major
                 gemm_bf16(1, 1, N, K, M, dyb, dyb.shape[1], xb, xb.shape[1], dW, K)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy, M, N)
-            return dx, dW, db, None
+            return dx, dW, db, None, None
         x, W = ctx.saved_tensors
         M, K = x.shape
         N = W.shape[0]
@@ -286,11 +295,14 @@ class LinearFn(torch.autograd.Function):
             gemm_nt_auto(N, K, M, dy, 1, N, x, 1, K, dW)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N)
-        return dx, dW, db, None
+        return dx, dW, db, None, None
 
 
 def linear(x, W, b=None, relu_input=False):
-    return LinearFn.apply(x, W, b, relu_input)
+    fused = None
+    if _fused and torch.is_grad_enabled() and W.requires_grad:
+        fused = fused_handle(W)
+    return LinearFn.apply(x, W, b, relu_input, fused)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1416,6 +1428,13 @@ class FusedAdamW(torch.optim.Optimizer):
             for k in [k for k, h in _fused.items() if h.param is None or h.opt is None]:
                 del _fused[k]
             _fused[id(p)] = FusedFirstLayer(self, p, group_of[id(p)])
+
+    def fuse_weight_update(self, *params):
+        """The same opt-in for any 2-D weight whose weight-gradient kernel can apply the AdamW step in its epilogue:
+        the sparse first layers (scp_spmm_dw_adamw_bf16) and the wide plain nn.Linear layers of precision 'bf16' (ZINB
+        G x G zero-inflation layer, VAE 900 <-> G layers: scp_gemm_bf16_adamw).  Same conditions as
+        fuse_first_layer; a layer that does not meet them in a given forward keeps the ordinary path."""
+        self.fuse_first_layer(*params)
 
     def unfuse(self):
         for g in self.param_groups:

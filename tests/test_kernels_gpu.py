@@ -482,6 +482,53 @@ def test_linear_wide_gemm_bf16(S, relu_in):
     S.ops.set_precision("fp32")
 
 
+def test_linear_wide_gemm_fused_adamw_equals_two_kernel_path(S):
+    """FusedAdamW.fuse_weight_update on a wide nn.Linear (scp_gemm_bf16_adamw: AdamW step in the epilogue of the
+    weight-gradient GEMM) against the ordinary path (scp_gemm_bf16 + scp_adamw_multi) over three steps: weights and
+    moments within 2e-6 relative to the largest weight (hardware sqrt / reciprocal in the fused update, ~1 ulp each),
+    the shadow exactly bf16(W), the same input gradient, and no .grad on the fused weight."""
+    ops = S.ops
+    ops.set_precision("bf16")
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 300, 2052, 1804                      # ragged tiles in both dimensions, K % 4 == 0
+    assert M * N * K >= ops._LIB_GEMM_MIN
+    W0 = torch.randn(N, K, generator=g) * 0.05
+    b0 = torch.randn(N, generator=g) * 0.1
+    xs = [torch.randn(M, K, generator=g).to(S.dev) for _ in range(3)]
+    dys = [torch.randn(M, N, generator=g).to(S.dev) * 0.01 for _ in range(3)]
+    res = {}
+    for mode in ("plain", "fused"):
+        W = torch.nn.Parameter(W0.clone().to(S.dev)); b = torch.nn.Parameter(b0.clone().to(S.dev))
+        opt = ops.FusedAdamW([{"params": [W], "weight_decay": 1e-2, "lr": 1e-2}, {"params": [b], "weight_decay": 0.0, "lr": 1e-2}])
+        if mode == "fused":
+            opt.fuse_weight_update(W)
+        dxs = []
+        for x, dy in zip(xs, dys):
+            xr = x.clone().requires_grad_(True)
+            opt.zero_grad()
+            ops.linear(xr, W, b).backward(dy)
+            if mode == "fused":
+                assert W.grad is None
+            dxs.append(xr.grad.clone())
+            opt.step()
+        st = opt.state[W]
+        res[mode] = (W.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), ops.shadow_of(W, create=False).clone(),
+                     dxs, b.detach().clone(), st["step"])
+    scale = float(W0.abs().max())
+    for i, what in enumerate(("W", "exp_avg", "exp_avg_sq")):
+        a_, r_ = res["fused"][i], res["plain"][i]
+        tol = 2e-6 * max(scale if i == 0 else float(r_.abs().max()), 1e-30)
+        assert float((a_ - r_).abs().max()) <= tol, (what, float((a_ - r_).abs().max()), tol)
+    assert torch.equal(res["fused"][3][:, :K], res["fused"][0].bfloat16())
+    # the second and third products read weights that differ by the update's rounding: bf16 shadows may flip one ulp
+    assert torch.equal(res["fused"][4][0], res["plain"][4][0])
+    for a_, r_ in zip(res["fused"][4][1:], res["plain"][4][1:]):
+        close(a_, r_.double(), rtol=1e-3, atol=1e-3 * float(r_.abs().max()), what="dx after fused steps")
+    assert torch.equal(res["fused"][5], res["plain"][5]) and res["fused"][6] == res["plain"][6] == 3
+    assert float((res["fused"][0] - W0.to(S.dev)).abs().max()) > 1e-3
+    ops.set_precision("fp32")
+
+
 def test_linear_relu_input_small_shapes_equal_torch(S):
     """relu_input on the small-shape path (hand-written split-bf16 GEMM, fp32-equivalent) against torch autograd."""
     g = torch.Generator().manual_seed(6)
