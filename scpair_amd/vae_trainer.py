@@ -81,11 +81,9 @@ class scVAE_object:
         if self.grad_sync is None:
             if self.fuse_optimizer:
                 opt.fuse_first_layer(*firsts)
-                # the decoder's 900 -> G heads (pairedVAE.py:111-119): AdamW step inside their weight-gradient GEMMs
-                wide = [m.weight for m in (getattr(dec, n_, None) for n_ in ("output", "output_inverse_dispersion", "output_dropout"))
-                        if isinstance(m, torch.nn.Linear) and m.weight.requires_grad]
-                if wide:
-                    opt.fuse_weight_update(*wide)
+                # (the decoder's 900 -> G heads keep the two-kernel update: fused into their weight-gradient GEMMs the
+                # step measured 1.95 ms against 1.79 -- 900 columns leave a quarter of the tiles ragged and the short
+                # K loop cannot hide the epilogue's HBM traffic)
         elif self.grad_sync.compress and ops.get_precision() == "bf16":
             opt._dp_sink = self.grad_sync.make_sink(firsts)
         return opt
