@@ -259,6 +259,20 @@ int scp_raw_rows_bwd(const float* z, long ldz, const float* tz, long ldt, const 
                      long ldy, const float* L, const float* lse, const float* T, const float* gout, int B, int G, int fast,
                      float* dz, long lddz, float* dtz, long lddt, float* dpi, long lddp, float* dL, void* stream);
 
+/* The predictor's head with per-feature parameters (model.py:239-252): fs [G] = feature_scalar of feature_factor=True
+ * (scale = softmax(relu(z) * sigmoid(fs))), thp [G] = output_inverse_dispersion of dispersion='feature'
+ * (theta = exp(thp) instead of exp(relu(z))); either may be null.  bwd also writes dfs [G] / dthp [G] (nullable): column
+ * sums over the cells, taken over fixed chunks of 16 rows into ws (scp_raw_rows_feat_ws_floats floats) and added in
+ * chunk order (bitwise reproducible). */
+long scp_raw_rows_feat_ws_floats(int B, int G);
+int scp_raw_rows_feat_fwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy, const float* L,
+                          const float* fs, const float* thp, int B, int G, int fast, float* lse, float* T, double* part,
+                          float* loss, void* stream);
+int scp_raw_rows_feat_bwd(const float* z, long ldz, const float* pi, long ldp, const float* y, long ldy, const float* L,
+                          const float* fs, const float* thp, const float* lse, const float* T, const float* gout, int B,
+                          int G, int fast, float* dz, long lddz, float* dpi, long lddp, float* dL, float* dfs, float* dthp,
+                          float* ws, void* stream);
+
 /* ---- evaluation metrics (evaluator.py:14-71): neighbour counts behind FOSCTTM / FOSFTTM for paired embeddings
  *      x, y [n][d]: lt12[i] = #{j: D[i][j] < D[i][i]}, lt21[i] = #{j: D[j][i] < D[i][i]},
  *      gt12[i] = #{j: D[i][j] > D[i][i]} with D the direct-form squared distances; diag_ws: n floats ---- */

@@ -96,6 +96,9 @@ _SIGS = {
     "scp_relu_softmax_rows": (I, [P, L, I, I, P, I, P, L, P, L, I, P]),
     "scp_raw_rows_fwd": (I, [P, L, P, L, P, L, P, L, P, I, I, I, P, P, P, P, P]),
     "scp_raw_rows_bwd": (I, [P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, P, L, P, L, P, L, P, P]),
+    "scp_raw_rows_feat_ws_floats": (L, [I, I]),
+    "scp_raw_rows_feat_fwd": (I, [P, L, P, L, P, L, P, P, P, I, I, I, P, P, P, P, P]),
+    "scp_raw_rows_feat_bwd": (I, [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, P, L, P, L, P, P, P, P, P]),
     "scp_fos_counts": (I, [P, L, P, L, I, I, P, P, P, P, P]),
     "scp_adamw_multi": (I, [C.POINTER(AdamTensor), I, F, F, F, P]),
     "scp_step_state_set": (I, [P, U64, F, F, P]),

@@ -225,8 +225,8 @@ class Output_Module_Raw(nn.Module):
 
     def fused_loss(self, latent_rep, output_batch, lib, latent_lib, labels, likelihood="nb"):
         """raw_loss(labels, *forward(...)): likelihood 'nb' in three fused decoder passes (row softmax statistics,
-        likelihood, gradients); 'zinb' through the materialised pre-activations and the fused row kernels.  Returns
-        None for the combinations without a fused form (feature factor / feature dispersion with 'zinb')."""
+        likelihood, gradients); 'zinb' through the materialised pre-activations and the fused row kernels (feature factor
+        and dispersion 'feature' included).  Returns None for the combinations without a fused form."""
         if likelihood not in ("nb", "zinb"):
             return None
         h = _cat_cov(latent_rep, output_batch)
@@ -237,7 +237,7 @@ class Output_Module_Raw(nn.Module):
             # The G x G zero-inflation layer needs px_mu as a GEMM operand, so the pre-activations are materialised:
             # z = Linear(h) (MFMA GEMM), px_mu = relu(z), pi = Linear_GxG(px_mu) (hand-written wide MFMA GEMM in bf16 mode), then
             # softmax / exp / ZINB likelihood and their backward in the fused row kernels.
-            if fs is not None or thp is not None or self.zero_inflated != True:  # noqa: E712
+            if self.zero_inflated != True:  # noqa: E712
                 return None
             if self.sample_factor == True:  # noqa: E712
                 L = lib
@@ -248,7 +248,7 @@ class Output_Module_Raw(nn.Module):
                                 "'infer_library_size' parameter for the raw counts decoder is set to True.")
             z = ops.linear(h, lin.weight, lin.bias)
             pi = self.output_dropout(z, relu_input=True)          # Linear(relu(z)), model.py:240,255-256
-            return ops.raw_rows_loss(z, pi, L, labels.to_dense())
+            return ops.raw_rows_loss(z, pi, L, labels.to_dense(), fs=fs, thp=thp)
         if self.sample_factor == True:  # noqa: E712
             L, lat = lib, None
         elif latent_lib is not None:

@@ -1147,7 +1147,61 @@ class RawRowsLossFn(torch.autograd.Function):
         return dz, dpi, (None if dL is None else dL.reshape(ctx.l_shape)), None, dtz
 
 
-def raw_rows_loss(z, pi, L, y, tz=None):
+class RawRowsFeatLossFn(torch.autograd.Function):
+    """The predictor's (ZI)NB head with per-feature parameters (model.py:239-252): fs = feature_scalar
+    (scale = softmax(relu(z) * sigmoid(fs))), thp = output_inverse_dispersion (theta = exp(thp), dispersion 'feature');
+    either may be None.  Same row kernels as RawRowsLossFn plus a column-parallel kernel for dfs / dthp."""
+
+    @staticmethod
+    def forward(ctx, z, pi, L, y, fs, thp):
+        lib = _lib.lib()
+        z, y = _f32c(z), _f32c(y)
+        pi = None if pi is None else _f32c(pi)
+        fs = None if fs is None else _f32c(fs)
+        thp = None if thp is None else _f32c(thp)
+        Lr = _f32c(L).reshape(-1)
+        _lib.require_cuda(z, y, Lr, pi, fs, thp)
+        B, G = z.shape
+        if y.shape != z.shape or Lr.numel() != B or (pi is not None and pi.shape != z.shape) or \
+                (fs is not None and fs.numel() != G) or (thp is not None and thp.numel() != G):
+            raise ValueError("raw_rows_loss: shape mismatch")
+        fast = 1 if get_precision() == "bf16" else 0
+        lse, T = _empty((B,), z), _empty((B,), z)
+        part = torch.empty(B, dtype=torch.float64, device=z.device)
+        loss = _empty((1,), z)
+        _lib.check(lib.scp_raw_rows_feat_fwd(z.data_ptr(), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(), _lib.ptr(fs),
+                                             _lib.ptr(thp), B, G, fast, lse.data_ptr(), T.data_ptr(), part.data_ptr(),
+                                             loss.data_ptr(), _lib.stream()), "scp_raw_rows_feat_fwd")
+        ctx.save_for_backward(z, pi, Lr, y, lse, T, fs, thp)
+        ctx.l_shape, ctx.fast = L.shape, fast
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.lib()
+        z, pi, Lr, y, lse, T, fs, thp = ctx.saved_tensors
+        B, G = z.shape
+        g = _f32c(g).reshape(1)
+        dz = torch.empty_like(z)
+        dpi = None if pi is None else torch.empty_like(pi)
+        dL = _empty((B,), z) if ctx.needs_input_grad[2] else None
+        dfs = torch.empty_like(fs) if (fs is not None and ctx.needs_input_grad[4]) else None
+        dthp = torch.empty_like(thp) if (thp is not None and ctx.needs_input_grad[5]) else None
+        ws = None
+        if dfs is not None or dthp is not None:
+            ws = _empty((lib.scp_raw_rows_feat_ws_floats(B, G),), z)
+        _lib.check(lib.scp_raw_rows_feat_bwd(z.data_ptr(), G, _lib.ptr(pi), G, y.data_ptr(), G, Lr.data_ptr(), _lib.ptr(fs),
+                                             _lib.ptr(thp), lse.data_ptr(), T.data_ptr(), g.data_ptr(), B, G, ctx.fast,
+                                             dz.data_ptr(), G, _lib.ptr(dpi), G, _lib.ptr(dL), _lib.ptr(dfs), _lib.ptr(dthp),
+                                             _lib.ptr(ws), _lib.stream()), "scp_raw_rows_feat_bwd")
+        return dz, dpi, (None if dL is None else dL.reshape(ctx.l_shape)), None, dfs, dthp
+
+
+def raw_rows_loss(z, pi, L, y, tz=None, fs=None, thp=None):
+    if fs is not None or thp is not None:
+        if tz is not None:
+            raise ValueError("raw_rows_loss: per-feature parameters belong to the predictor's head (tz must be None)")
+        return RawRowsFeatLossFn.apply(z, pi, L, y, fs, thp)
     return RawRowsLossFn.apply(z, pi, L, y, tz)
 
 

@@ -358,6 +358,88 @@ def test_zinb_row_loss_vs_oracle(S, B, F, K, sf):
         S.ops.set_precision("fp32")
 
 
+@pytest.mark.parametrize("ff,disp", [(True, "feature-cell"), (False, "feature"), (True, "feature")])
+@pytest.mark.parametrize("sf", [True, False])
+def test_zinb_row_loss_feature_parameters_vs_oracle(S, ff, disp, sf):
+    """ZINB predictor head with feature_factor=True and / or dispersion='feature' (model.py:239-252) on the fused row
+    kernels against the CPU oracle: loss, gradients of both Linear layers, of feature_scalar and of the per-feature
+    dispersion (column sums taken in fixed row chunks), of the latent input and the latent library size.  Tolerance:
+    loss 5e-5 relative, gradients 5e-4 of their largest element (fp32 mode; accumulation order differs)."""
+    O = S.O
+    S.ops.set_precision("fp32")
+    B, F, K = 70, 517, 12
+    rng = np.random.default_rng(F + 7)
+    g = torch.Generator().manual_seed(F + 7 + int(ff) + 2 * int(sf))
+    h = torch.randn(B, K, generator=g) * 0.5
+    W = torch.randn(F, K, generator=g) * 0.3; b = torch.randn(F, generator=g) * 0.5
+    Wp = torch.randn(F, F, generator=g) * (0.5 / F ** 0.5); bp = torch.randn(F, generator=g) * 0.5
+    fs0 = torch.randn(F, generator=g); th0 = torch.randn(F, generator=g) * 0.5
+    lat = torch.randn(B, 1, generator=g) + 4.0
+    yn = rand_csr(rng, B, F, 0.1)
+    ynd = torch.tensor(np.asarray(yn.todense(), dtype=np.float32))
+    lib = ynd.sum(1, keepdim=True)
+    ref = [t.clone().requires_grad_(True) for t in (h, W, b, Wp, bp, lat, fs0, th0)]
+    sd = {"output_mean.0.weight": ref[1], "output_mean.0.bias": ref[2], "output_dropout.weight": ref[3],
+          "output_dropout.bias": ref[4]}
+    if ff:
+        sd["feature_scalar"] = ref[6]
+    if disp == "feature":
+        sd["output_inverse_dispersion"] = ref[7]
+    _, theta, rate, pi = O.output_raw(sd, ref[0], None, lib if sf else None, None if sf else ref[5], sf, dispersion=disp)
+    lo = O.raw_loss(ynd, rate, theta, pi, "zinb"); lo.backward()
+    dec = S.pkg.model.Output_Module_Raw(F, 0, [K], infer_library_size=not sf, sample_factor=sf, feature_factor=ff,
+                                        dispersion=disp).to(S.dev)
+    with torch.no_grad():
+        dec.output_mean[0].weight.copy_(W); dec.output_mean[0].bias.copy_(b)
+        dec.output_dropout.weight.copy_(Wp); dec.output_dropout.bias.copy_(bp)
+        if ff:
+            dec.feature_scalar.copy_(fs0)
+        if disp == "feature":
+            dec.output_inverse_dispersion.copy_(th0)
+    hd, ld = h.clone().to(S.dev).requires_grad_(True), lat.clone().to(S.dev).requires_grad_(True)
+    tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(yn, S.dev), np.arange(B))
+    l = dec.fused_loss(hd, None, tiles.lib.reshape(-1, 1) if sf else None, None if sf else ld, tiles, "zinb")
+    assert l is not None, "the fused ZINB head must cover feature factor / feature dispersion"
+    l.backward()
+    close(l, lo, rtol=5e-5, atol=0, what="zinb loss")
+    pairs = [("dh", hd.grad, ref[0].grad), ("dW", dec.output_mean[0].weight.grad, ref[1].grad),
+             ("db", dec.output_mean[0].bias.grad, ref[2].grad), ("dWpi", dec.output_dropout.weight.grad, ref[3].grad),
+             ("dbpi", dec.output_dropout.bias.grad, ref[4].grad)]
+    if not sf:
+        pairs.append(("dlat", ld.grad, ref[5].grad))
+    if ff:
+        pairs.append(("dfs", dec.feature_scalar.grad, ref[6].grad))
+    if disp == "feature":
+        pairs.append(("dtheta", dec.output_inverse_dispersion.grad, ref[7].grad))
+    for nm, a, r_ in pairs:
+        close(a, r_, rtol=5e-4, atol=5e-4 * float(r_.abs().max()), what=f"zinb {nm}")
+    # the generic path (forward() + raw_loss) gives the same value, and a second backward the same bits
+    with torch.no_grad():
+        outs = dec(hd, None, tiles.lib.reshape(-1, 1) if sf else None, None if sf else ld)
+        lg = S.pkg.loss.raw_loss(x=tiles.to_dense(), px_mu_rate=outs[2], px_theta=outs[1], px_mu_scale=outs[0],
+                                 px_pi=outs[3], likelihood="zinb")
+    close(lg, lo, rtol=5e-5, atol=0, what="zinb loss (generic path)")
+    first = [a.clone() for _, a, _ in pairs]
+    for prm in dec.parameters():
+        prm.grad = None
+    hd.grad = None; ld.grad = None
+    dec.fused_loss(hd, None, tiles.lib.reshape(-1, 1) if sf else None, None if sf else ld, tiles, "zinb").backward()
+    again = [hd.grad, dec.output_mean[0].weight.grad, dec.output_mean[0].bias.grad, dec.output_dropout.weight.grad,
+             dec.output_dropout.bias.grad] + ([] if sf else [ld.grad]) + ([dec.feature_scalar.grad] if ff else []) + \
+            ([dec.output_inverse_dispersion.grad] if disp == "feature" else [])
+    for a_, b_ in zip(first, again):
+        assert torch.equal(a_, b_), "not bitwise reproducible"
+    # precision mode 'bf16': loss within 1e-2 relative
+    S.ops.set_precision("bf16")
+    try:
+        hb = h.clone().to(S.dev).requires_grad_(True)
+        lb = dec.fused_loss(hb, None, tiles.lib.reshape(-1, 1) if sf else None, None if sf else ld.detach(), tiles, "zinb")
+        lb.backward()
+        close(lb, lo, rtol=1e-2, atol=0, what="zinb loss (bf16 mode)")
+    finally:
+        S.ops.set_precision("fp32")
+
+
 def test_ber_eval_mode_matches_train_loss(S):
     S.ops.set_precision("fp32")
     d = U.load("mod_ber")
