@@ -2,7 +2,9 @@
 tools/make_goldens.py) against scpair_amd on the same synthetic inputs, seeds and initialisation.
 
 Tolerances:
-  fp32 path : per-step training loss rel 2e-4, per-epoch validation loss rel 2e-4, embeddings max-abs 2e-3
+  fp32 path : per-step training loss rel 1e-5, per-epoch validation loss rel 1e-4, embeddings max-abs 1e-3 (the values
+              SURVEY 8d states; measured on MI355X: <= 3e-6, <= 2.4e-6, <= 4e-4 with BatchNorm and <= 3.1e-5 without;
+              the test prints them)
   bf16 path : losses rel 2e-2, embeddings cosine median >= 0.999, 5th percentile >= 0.99 and min >= 0.99 (0.95 with
               BatchNorm; 8-dim toy embeddings)
 """
@@ -65,11 +67,14 @@ def test_trajectory_fp32(name):
     for di in range(2):
         h = obj.history[names[di] + " to " + names[1 - di]]
         assert len(h["train_loss"]) == len(d[f"dir{di}/train_loss"])
-        assert _rel(h["train_loss"], d[f"dir{di}/train_loss"]) < 2e-4, (di, _rel(h["train_loss"], d[f"dir{di}/train_loss"]))
-        assert _rel(h["val_loss"], d[f"dir{di}/val_loss"]) < 2e-4, (di, _rel(h["val_loss"], d[f"dir{di}/val_loss"]))
+        print(f"[measured] {name} dir{di}: train loss rel {_rel(h['train_loss'], d[f'dir{di}/train_loss']):.2e}, "
+              f"val loss rel {_rel(h['val_loss'], d[f'dir{di}/val_loss']):.2e}", flush=True)
+        assert _rel(h["train_loss"], d[f"dir{di}/train_loss"]) < 1e-5, (di, _rel(h["train_loss"], d[f"dir{di}/train_loss"]))
+        assert _rel(h["val_loss"], d[f"dir{di}/val_loss"]) < 1e-4, (di, _rel(h["val_loss"], d[f"dir{di}/val_loss"]))
     emb, _ = obj.reference_embeddings()
     for k, v in emb.items():
-        assert float((v - torch.tensor(d["emb/" + k])).abs().max()) < 2e-3, k
+        print(f"[measured] {name} embedding {k}: max abs {float((v - torch.tensor(d['emb/' + k])).abs().max()):.2e}", flush=True)
+        assert float((v - torch.tensor(d["emb/" + k])).abs().max()) < 1e-3, k
     if name in ("traj_nb_ber", "traj_zinb_ber"):
         obj.train_bidirectional_mapping()
         for mi in range(2):
