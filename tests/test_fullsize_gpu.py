@@ -186,3 +186,56 @@ def test_vae_step_c4_shape(lik):
         if r is None or p.grad is None:
             continue
         assert _scale_err(p.grad, r) < 1e-3, (k, _scale_err(p.grad, r))
+
+
+def test_wide_linear_c3_shape_against_dense_matmuls():
+    """The ZINB zero-inflation layer at its C3 size (20 000 -> 20 000, batch 1024; model.py:228,255-256) on the
+    hand-written wide GEMM: forward with bias, input gradient with the relu mask, weight gradient, each against torch's
+    fp32 matmul of the same bf16-rounded operands on the device.  Both sides add 20 000 (1 024 for the weight
+    gradient) exact products in fp32 in different orders: 2e-5 of the output scale is stated.  Then the same layer with
+    the AdamW step in the weight-gradient epilogue (scp_gemm_bf16_adamw) against the formula applied to that gradient."""
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision("bf16")
+    try:
+        G, B = 20000, 1024
+        g_ = torch.Generator(device=DEV).manual_seed(3)
+        x = torch.randn(B, G, device=DEV, generator=g_)
+        W = torch.nn.Parameter(torch.randn(G, G, device=DEV, generator=g_) * 0.01)
+        b = torch.nn.Parameter(torch.randn(G, device=DEV, generator=g_))
+        dy = torch.randn(B, G, device=DEV, generator=g_)
+        xr = x.clone().requires_grad_(True)
+        y = ops.linear(xr, W, b, relu_input=True)
+        y.backward(dy)
+        xb = torch.relu(x).bfloat16().float()
+        Wb = W.detach().bfloat16().float()
+        dyb = dy.bfloat16().float()
+        assert _scale_err(y, xb @ Wb.t() + b.detach()) < 2e-5
+        assert _scale_err(xr.grad, (dyb @ Wb) * (xb > 0)) < 2e-5
+        dW_ref = dyb.t() @ xb
+        assert _scale_err(W.grad, dW_ref) < 2e-5
+        del y, xr, Wb
+        # AdamW in the epilogue: one step from zero moments
+        lr, wd, b1, b2, eps = 1e-3, 1e-2, 0.9, 0.999, 1e-8
+        W0 = W.detach().clone()
+        W.grad = None
+        opt = ops.FusedAdamW([{"params": [W], "weight_decay": wd, "lr": lr}], betas=(b1, b2), eps=eps)
+        opt.fuse_weight_update(W)
+        xr = x.clone().requires_grad_(True)
+        ops.linear(xr, W, None, relu_input=True).backward(dy)
+        assert W.grad is None
+        opt.step()
+        m = (1 - b1) * dW_ref
+        v = (1 - b2) * dW_ref * dW_ref
+        Wn = W0 * (1 - lr * wd) - (lr / (1 - b1)) * m / (v.sqrt() / (1 - b2) ** 0.5 + eps)
+        st = opt.state[W]
+        assert _scale_err(st["exp_avg"], m) < 5e-5 and _scale_err(st["exp_avg_sq"], v) < 5e-5
+        # the first step from zero moments is lr * g / (|g| + eps'): where g is within rounding of zero its sign, and
+        # with it the whole update, is decided by the summation order -- compare the applied change elsewhere
+        ok = dW_ref.abs() > 1e-3 * float(dW_ref.abs().max())
+        assert float(ok.float().mean()) > 0.99
+        err = ((W.detach() - W0) - (Wn - W0)).abs()[ok].max()
+        assert float(err) < 2e-3 * lr, float(err)
+        assert torch.equal(ops.shadow_of(W, create=False)[:, :G], W.detach().bfloat16())
+    finally:
+        S.set_precision("fp32")
