@@ -21,6 +21,9 @@ dec = S.VAE_DECODER(input_dim=G, input_batch_num=0, hidden_dim=[900], latent_dim
 opt = S.FusedAdamW(list(enc.parameters()) + list(dec.parameters()), lr=1e-3, weight_decay=0.0)
 if os.environ.get("FUSE", "1") == "1":
     opt.fuse_first_layer(enc.enc_hidden[0].weight)      # AdamW step of the 900 x 20 k encoder weights in their dW kernel
+    if os.environ.get("FUSE_WIDE", "0") == "1":         # experiment: also the decoder's 900 -> 20 k heads (measured slower)
+        opt.fuse_weight_update(*[m.weight for m in (getattr(dec, n_, None) for n_ in ("output", "output_inverse_dispersion", "output_dropout"))
+                                 if isinstance(m, torch.nn.Linear)])
 enc.train(); dec.train()
 rng = np.random.default_rng(0)
 def step():

@@ -272,9 +272,10 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const long idx = (long)(mrow + 2 * (it0 + u)) * g.ldc + n;
-            pv[u] = *(const f4*)(g.C + idx);
-            mv[u] = *(const f4*)(g.adam_m + idx);
-            vv[u] = *(const f4*)(g.adam_v + idx);
+            // read once and written once per step, 10 GB in all: streaming accesses, nothing to keep in the caches
+            pv[u] = __builtin_nontemporal_load((const f4*)(g.C + idx));
+            mv[u] = __builtin_nontemporal_load((const f4*)(g.adam_m + idx));
+            vv[u] = __builtin_nontemporal_load((const f4*)(g.adam_v + idx));
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
@@ -291,9 +292,9 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
               vv[u][t] = v_;
               sh4[t] = (__bf16)p_;
             }
-            *(f4*)(g.C + idx) = pv[u];
-            *(f4*)(g.adam_m + idx) = mv[u];
-            *(f4*)(g.adam_v + idx) = vv[u];
+            __builtin_nontemporal_store(pv[u], (f4*)(g.C + idx));
+            __builtin_nontemporal_store(mv[u], (f4*)(g.adam_m + idx));
+            __builtin_nontemporal_store(vv[u], (f4*)(g.adam_v + idx));
             *(bf16x4*)(g.adam_sh + (long)(mrow + 2 * (it0 + u)) * g.adam_ldsh + n) = sh4;
           }
         }
