@@ -7,8 +7,8 @@
 // products of a Linear layer run on the operands as they lie in memory, without a transposed copy:
 //   y  = x W^T   : A = x  row, B = W row        dx = dy W : A = dy row, B = W col        dW = dy^T x : A = dy col, B = x col
 //
-// Workgroup: 256 threads = 2 x 2 waves, tile 256 x 256 x 64, every wave 128 x 128 = 4 x 4 accumulators of the
-// 32x32x16 bf16 MFMA (256 accumulator registers; one wave per SIMD, 512 registers per lane).  Operand tiles go
+// Workgroup: tile 256 x 256 x 64 on 512 threads = 2 x 4 waves of 128 x 64 (4 x 2 accumulators of the 32x32x16 bf16
+// MFMA, two waves per SIMD) or on 256 threads = 2 x 2 waves of 128 x 128 (one wave per SIMD).  Operand tiles go
 // global -> registers (16-byte buffer loads, the range check supplies the zeros of ragged edges) -> LDS, two LDS
 // stages of 64 KB, one barrier per K-step: the next step's global loads are in flight while this step's 64 MFMAs run.
 //   row image  [256][64]  : 128-byte rows, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7); read with ds_read_b128
@@ -80,12 +80,16 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* img, int r0, in
 
 enum { EPI_SLAB = 0, EPI_DIRECT = 1, EPI_ADAMW = 2 };
 
-template <bool A_COL, bool B_COL, int EPI>
-__global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
+// NW = 8 (default for the plain products): two waves per SIMD, wave tile 128 x 64, one register set of prefetched tiles
+// (256 registers per lane): one wave's MFMA groups cover the other's waits.  NW = 4 (the AdamW form; SCPAIR_WGEMM_NW=4
+// elsewhere): one wave per SIMD, wave tile 128 x 128, two register sets (loads two K-steps ahead).
+template <bool A_COL, bool B_COL, int EPI, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void wgemm_kernel(WgArgs g) {
   constexpr bool DIRECT = EPI == EPI_DIRECT;
+  constexpr int NJ = NW == 4 ? 4 : 2, WN = 32 * NJ, CH = 32 / NW, LSTEP = 1024 * NW, NSET = NW == 4 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
 
   // XCD-aware id: ids b, b+8, b+16.. run on one XCD -> give them consecutive tiles
   const int total = g.tiles_m * g.tiles_n * g.nsplit;
@@ -111,30 +115,30 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
   const int rB = B_COL ? (tid >> 5) : (tid >> 3), cB = B_COL ? (tid & 31) : (tid & 7);
   const unsigned baseA = A_COL ? (unsigned)(((long)rA * g.lda + m0 + 8 * cA) * 2) : (unsigned)(((long)(m0 + rA) * g.lda + 8 * cA) * 2);
   const unsigned baseB = B_COL ? (unsigned)(((long)rB * g.ldb + n0 + 8 * cB) * 2) : (unsigned)(((long)(n0 + rB) * g.ldb + 8 * cB) * 2);
-  const unsigned stepA = (unsigned)((A_COL ? 8 : 32) * g.lda * 2), stepB = (unsigned)((B_COL ? 8 : 32) * g.ldb * 2);
+  const unsigned stepA = (unsigned)((A_COL ? 8 : 32) * (NW / 4) * g.lda * 2), stepB = (unsigned)((B_COL ? 8 : 32) * (NW / 4) * g.ldb * 2);
   const int ldsA0 = A_COL ? col_off(rA, 8 * cA) : row_off(rA, cA);
   const int ldsB0 = B_COL ? col_off(rB, 8 * cB) : row_off(rB, cB);
   // Ragged edges come from the buffer's range check: a row image's rows >= M and a col image's k rows >= K start at
   // or beyond the operand's last byte and load as zeros.  Only the k tail of a row image needs a test (it would run
   // into the next row): those chunks get the top offset bit.  A col image's columns beyond ld wrap into the next k
   // row; they only feed output rows >= M, which are not stored.
-  unsigned offA[8], offB[8];
+  unsigned offA[CH], offB[CH];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
+  for (int i = 0; i < CH; i++) {
     offA[i] = baseA + stepA * i;
     offB[i] = baseB + stepB * i;
   }
 
   // two register sets: the loads of K-step kt + 2 are issued during step kt and stored to LDS during step kt + 1,
   // so a load has more than a whole K-step (64 MFMAs) to arrive
-  u32x4 ra[2][8], rb[2][8];
+  u32x4 ra[NSET][CH], rb[NSET][CH];
   auto load_tiles = [&](int kt, int set) {       // kt >= kt1: out of range, zeros
     const int k0 = kt * TK;
     const unsigned dead = (kt < kt1 ? 0u : OOR) | g.dbg_oor;
     const unsigned kA = (A_COL ? (unsigned)((long)k0 * g.lda * 2) : ((k0 + 8 * cA < Kp) ? (unsigned)k0 * 2u : OOR)) | dead;
     const unsigned kB = (B_COL ? (unsigned)((long)k0 * g.ldb * 2) : ((k0 + 8 * cB < Kp) ? (unsigned)k0 * 2u : OOR)) | dead;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < CH; i++) {
       ra[set][i] = ld128(rsA, offA[i] + kA);
       rb[set][i] = ld128(rsB, offB[i] + kB);
     }
@@ -143,34 +147,34 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
     unsigned char* ia = smem + stage * STAGE_BYTES;
     unsigned char* ib = ia + TM * TK * 2;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      *(u32x4*)(ia + ldsA0 + 4096 * i) = ra[set][i];
-      *(u32x4*)(ib + ldsB0 + 4096 * i) = rb[set][i];
+    for (int i = 0; i < CH; i++) {
+      *(u32x4*)(ia + ldsA0 + LSTEP * i) = ra[set][i];
+      *(u32x4*)(ib + ldsB0 + LSTEP * i) = rb[set][i];
     }
   };
 
-  f32x16 acc[4][4];
+  f32x16 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  bf16x8 fa[2][4], fb[2][4];
+  bf16x8 fa[2][4], fb[2][NJ];
   auto read_frags = [&](int stage, int s, int set) {
     const unsigned char* ia = smem + stage * STAGE_BYTES;
     const unsigned char* ib = ia + TM * TK * 2;
 #pragma unroll
     for (int i = 0; i < 4; i++) fa[set][i] = read_frag<A_COL>(ia, wm * 128 + 32 * i, s, lane);
 #pragma unroll
-    for (int j = 0; j < 4; j++) fb[set][j] = read_frag<B_COL>(ib, wn * 128 + 32 * j, s, lane);
+    for (int j = 0; j < NJ; j++) fb[set][j] = read_frag<B_COL>(ib, wn * WN + 32 * j, s, lane);
   };
   auto products = [&](int set) {
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = mfma32(fa[set][i], fb[set][j], acc[i][j]);
+      for (int j = 0; j < NJ; j++) acc[i][j] = mfma32(fa[set][i], fb[set][j], acc[i][j]);
   };
   // instruction classes of __builtin_amdgcn_sched_group_barrier
   constexpr int MFMA = 0x008, VMEM_RD = 0x020, DS_RD = 0x100, DS_WR = 0x200;
@@ -178,72 +182,55 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
 
   load_tiles(kt0, 0);
   store_tiles(0, 0);
-  load_tiles(kt0 + 1, 1);
+  if (NSET == 2) load_tiles(kt0 + 1, 1);
   __syncthreads();
-  // One K-step = four MFMA groups of 16 products.  The fragments of group s + 1 are read while group s multiplies,
-  // the 16 global loads of step kt + 2 are spread over group 0 and the 16 LDS stores of step kt + 1's tiles over
-  // group 3 (the other stage: nobody reads it before the barrier), so the matrix pipe always has the next group's
-  // operands in registers.  Two steps per trip (static register sets); an odd range runs one step on zero tiles.
+  // One K-step = four MFMA groups of 4 x NJ products.  The fragments of group s + 1 are read while group s multiplies,
+  // the global loads of a later step (kt + 2 with two register sets, kt + 1 with one) are spread over group 0 and the
+  // LDS stores of step kt + 1's tiles over group 3 (the other stage: nobody reads it before the barrier), so the
+  // matrix pipe always has the next group's operands in registers.  Two steps per trip (static register sets); an
+  // odd range runs one step on zero tiles.
+#define WG_SCHED(VM)                                                                 \
+  _Pragma("unroll") for (int t = 0; t < 4; t++) {                                    \
+    if (VM) __builtin_amdgcn_sched_group_barrier(VMEM_RD, 2, 0);                     \
+    __builtin_amdgcn_sched_group_barrier(DS_RD, RD_A, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(MFMA, NJ == 4 ? 2 : 1, 0);                  \
+  }                                                                                  \
+  _Pragma("unroll") for (int t = 0; t < NJ; t++) {                                   \
+    if (VM && NJ == 4) __builtin_amdgcn_sched_group_barrier(VMEM_RD, 2, 0);          \
+    __builtin_amdgcn_sched_group_barrier(DS_RD, RD_B, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);                                \
+  }                                                                                  \
+  __builtin_amdgcn_sched_barrier(0);
   auto k_step = [&](int kt, int stage, int set_ld, int set_st) {
     read_frags(stage, 0, 0);
-    load_tiles(kt + 2, set_ld);
+    load_tiles(kt + NSET, set_ld);
     read_frags(stage, 1, 1);
     products(0);
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      __builtin_amdgcn_sched_group_barrier(VMEM_RD, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_A, 0);
-      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      __builtin_amdgcn_sched_group_barrier(VMEM_RD, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_B, 0);
-      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    WG_SCHED(true)
     read_frags(stage, 2, 0);
     products(1);
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_A, 0);
-      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_B, 0);
-      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    WG_SCHED(false)
     read_frags(stage, 3, 1);
     products(0);
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_A, 0);
-      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      __builtin_amdgcn_sched_group_barrier(DS_RD, RD_B, 0);
-      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    WG_SCHED(false)
     store_tiles(stage ^ 1, set_st);
     products(1);
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
+    for (int t = 0; t < 2 * CH; t++) {
       __builtin_amdgcn_sched_group_barrier(DS_WR, 1, 0);
       __builtin_amdgcn_sched_group_barrier(MFMA, 1, 0);
     }
     __syncthreads();
   };
+#undef WG_SCHED
   for (int kt = kt0; kt < kt1; kt += 2) {
-    k_step(kt, 0, 0, 1);
-    k_step(kt + 1, 1, 1, 0);
+    k_step(kt, 0, 0, NSET - 1);
+    k_step(kt + 1, 1, NSET - 1, 0);
   }
 
   // epilogue: accumulator element e of lane l is row acc_row(e, l), column l & 31 of its 32 x 32 tile
-  if (EPI == EPI_ADAMW) {
+  if constexpr (EPI == EPI_ADAMW) {
+    static_assert(NW == 4, "the AdamW epilogue is written for the four-wave tile");
     // The tile is a block of the weight gradient: apply torch.optim.AdamW's update to the master weights, the moments
     // and the bf16 shadow right here; the gradient never reaches HBM.  Every wave passes its 32-row strips through a
     // private LDS buffer [32][132] (the operand stages are free after the loop's last barrier; same-wave LDS accesses
@@ -332,8 +319,8 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
   if (m0 + TM <= g.M && n0 + TN <= g.N && !(DIRECT && g.mask)) {
     // interior tile: no tests; one store instruction writes two 128-byte row segments
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int n = n0 + wn * 128 + 32 * j + (lane & 31);
+    for (int j = 0; j < NJ; j++) {
+      const int n = n0 + wn * WN + 32 * j + (lane & 31);
       const float bn = (DIRECT && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -351,8 +338,8 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
     const __amdgpu_buffer_rsrc_t rsM =
         __builtin_amdgcn_make_buffer_rsrc((void*)(DIRECT && g.mask ? g.mask : g.A), 0, (int)g.m_bytes, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int n = n0 + wn * 128 + 32 * j + (lane & 31);
+    for (int j = 0; j < NJ; j++) {
+      const int n = n0 + wn * WN + 32 * j + (lane & 31);
       const unsigned colbad = n < g.N ? 0u : OOR;
       const float bn = (DIRECT && g.bias && n < g.N) ? g.bias[n] : 0.f;
 #pragma unroll
@@ -376,8 +363,8 @@ __global__ __launch_bounds__(256) void wgemm_kernel(WgArgs g) {
     return;
   }
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int n = n0 + wn * 128 + 32 * j + (lane & 31);
+  for (int j = 0; j < NJ; j++) {
+    const int n = n0 + wn * WN + 32 * j + (lane & 31);
     if (n >= g.N) continue;
     const float bn = (DIRECT && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
@@ -456,14 +443,27 @@ int launch(const WgArgs& g, hipStream_t st) {
   static uint64_t done_d = 0, done_s = 0;
   const int total = g.tiles_m * g.tiles_n * g.nsplit;
   const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-  if (g.nsplit == 1) {
+  static uint64_t done_d8 = 0, done_s8 = 0;
+  // eight waves by default (measured 2-10 % faster than four on every shape of the wide layers, same box, back to
+  // back); SCPAIR_WGEMM_NW=4 selects the four-wave form for comparison
+  const char* e8 = getenv("SCPAIR_WGEMM_NW");
+  const bool nw8 = !(e8 && atoi(e8) == 4);
+  if (g.nsplit == 1 && !nw8) {
     int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, EPI_DIRECT>, 2 * STAGE_BYTES, &done_d);
     if (rc) return rc;
     hipLaunchKernelGGL((wgemm_kernel<AC, BC, EPI_DIRECT>), dim3(grid), dim3(256), 2 * STAGE_BYTES, st, g);
-  } else {
+  } else if (!nw8) {
     int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, EPI_SLAB>, 2 * STAGE_BYTES, &done_s);
     if (rc) return rc;
     hipLaunchKernelGGL((wgemm_kernel<AC, BC, EPI_SLAB>), dim3(grid), dim3(256), 2 * STAGE_BYTES, st, g);
+  } else if (g.nsplit == 1) {
+    int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, EPI_DIRECT, 8>, 2 * STAGE_BYTES, &done_d8);
+    if (rc) return rc;
+    hipLaunchKernelGGL((wgemm_kernel<AC, BC, EPI_DIRECT, 8>), dim3(grid), dim3(512), 2 * STAGE_BYTES, st, g);
+  } else {
+    int rc = scp_set_smem((const void*)wgemm_kernel<AC, BC, EPI_SLAB, 8>, 2 * STAGE_BYTES, &done_s8);
+    if (rc) return rc;
+    hipLaunchKernelGGL((wgemm_kernel<AC, BC, EPI_SLAB, 8>), dim3(grid), dim3(512), 2 * STAGE_BYTES, st, g);
   }
   SCP_LAUNCH_CHECK();
   return SCP_OK;
