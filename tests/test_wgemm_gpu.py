@@ -79,3 +79,27 @@ def test_wide_gemm_rejects_misaligned_operands():
         ops.gemm_bf16(0, 0, 64, 64, 70, A, 70, B, 72, C, 64)        # lda not a multiple of 8
     with pytest.raises((ValueError, RuntimeError)):
         ops.gemm_bf16(0, 0, 64, 64, 80, A, 72, B, 72, C, 64)        # lda smaller than K
+
+
+def test_wide_gemm_output_of_two_gib_and_more():
+    """An output of 2 GiB or more cannot go through 32-bit buffer offsets: edge and masked tiles then take the guarded
+    64-bit stores.  27 000 x 20 000 fp32 (2.16 GB, ragged in both dimensions) with bias and mask, short K."""
+    from scpair_amd import ops
+    dev = torch.device("cuda:0")
+    M, N, K = 27000, 20000, 64
+    gen = torch.Generator(device=dev).manual_seed(11)
+    A = torch.randn((M, K), device=dev, generator=gen).to(torch.bfloat16)
+    B = torch.randn((N, K), device=dev, generator=gen).to(torch.bfloat16)
+    bias = torch.randn((N,), device=dev, generator=gen)
+    mask = (torch.randn((M, N), device=dev, generator=gen) - 0.3).to(torch.bfloat16)
+    C = torch.full((M, N), 7.0, device=dev)
+    assert C.numel() * 4 >= 1 << 31
+    ops.gemm_bf16(0, 0, M, N, K, A, K, B, K, C, N, bias=bias, mask=mask, ldm=N)
+    want = A.float() @ B.float().t() + bias
+    want = torch.where(mask.float() > 0, want, torch.zeros_like(want))
+    assert float((C - want).abs().max()) <= 2e-5 * 8 * 16.0
+    del want
+    C2 = torch.full((M, N), 7.0, device=dev)
+    ops.gemm_bf16(0, 0, M, N, K, A, K, B, K, C2, N)          # no mask: interior tiles plain stores, edge tiles guarded
+    want = A.float() @ B.float().t()
+    assert float((C2 - want).abs().max()) <= 2e-5 * 8 * 16.0
