@@ -1,11 +1,22 @@
-"""Times the hand-written wide bf16 GEMM (scp_gemm_bf16) beside rocBLAS (scp_gemm_lib_bf16) on the shapes of the wide
+"""Times the hand-written wide bf16 GEMM (scp_gemm_bf16) beside rocBLAS (benchmarks/rocblas_cmp: a benchmark-only library, not part of libscpair_hip.so) on the shapes of the wide
 nn.Linear layers: ZINB G x G (model.py:228) and VAE 900 <-> G (pairedVAE.py:111-119), batch 1024.
 usage: python benchmarks/wgemm_bench.py [G]"""
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import ctypes as C
 from scpair_amd import ops, _lib
+
+_cmp = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rocblas_cmp", "librocblas_cmp.so"))
+_cmp.cmp_gemm_rocblas_bf16.restype = C.c_int
+_cmp.cmp_gemm_rocblas_bf16.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
+
+
+def gemm_lib(ta, tb, m, n, k, A, lda, B, ldb, Cm, ldc):
+    rc = _cmp.cmp_gemm_rocblas_bf16(ta, tb, m, n, k, A.data_ptr(), lda, B.data_ptr(), ldb, Cm.data_ptr(), ldc, _lib.stream())
+    if rc:
+        raise RuntimeError(f"rocBLAS comparison GEMM failed ({rc})")
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 dev = torch.device("cuda:0")
@@ -42,11 +53,11 @@ def layer(M, N, K):
     bias = torch.randn((N,), device=dev)
     rows = [
         ("fwd y = x W^T", M, N, K, lambda: ops.gemm_bf16(0, 0, M, N, K, x, ldx, W, ldw, y, N, bias=bias),
-         lambda: ops.gemm_lib(1, 0, N, M, K, W, ldw, x, ldx, y, N)),
+         lambda: gemm_lib(1, 0, N, M, K, W, ldw, x, ldx, y, N)),
         ("dx = dy W", M, K, N, lambda: ops.gemm_bf16(0, 1, M, K, N, dy, ldy, W, ldw, dx, K),
-         lambda: ops.gemm_lib(0, 0, K, M, N, W, ldw, dy, ldy, dx, K)),
+         lambda: gemm_lib(0, 0, K, M, N, W, ldw, dy, ldy, dx, K)),
         ("dW = dy^T x", N, K, M, lambda: ops.gemm_bf16(1, 1, N, K, M, dy, ldy, x, ldx, dW, K),
-         lambda: ops.gemm_lib(0, 1, K, N, M, x, ldx, dy, ldy, dW, K)),
+         lambda: gemm_lib(0, 1, K, N, M, x, ldx, dy, ldy, dW, K)),
     ]
     for name, m, n, k, ours, lib in rows:
         t1, t2 = timeit(ours), timeit(lib)

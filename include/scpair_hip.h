@@ -86,13 +86,8 @@ int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const
 int scp_gemm_nt(int M, int N, int K, const float* A, long a_row_stride, long a_k_stride, const float* B,
                 long b_row_stride, long b_k_stride, float* C, long ldc, const float* bias /* [N] nullable */,
                 int accumulate, int nsplit, int ns, void* stream);
-/* rocBLAS bf16 GEMM on the shapes of the wide layers (ZINB G x G model.py:228, VAE 900<->G pairedVAE.py:111-119): the
- * comparison that benchmarks/wgemm_bench.py times beside scp_gemm_bf16 below; no product path calls it.
- * bf16 operands, fp32 accumulate/output.  Column-major BLAS convention, ta/tb: 0 = N, 1 = T; see libgemm.hip for the
- * three row-major nn.Linear cases */
-int scp_gemm_lib_bf16(int ta, int tb, int m, int n, int k, const void* A_bf16, long lda, const void* B_bf16, long ldb,
-                      float* C, long ldc, void* stream);
-/* The same wide layers on the hand-written MFMA kernel (csrc/wgemm.hip), replacing torch's addmm behind nn.Linear
+/* The wide layers (ZINB G x G model.py:228, VAE 900 <-> G pairedVAE.py:111-119) on the hand-written MFMA kernel
+ * (csrc/wgemm.hip), replacing torch's addmm behind nn.Linear
  * (model.py:228,255-256; pairedVAE.py:111-119) forward, input gradient and weight gradient:
  *   C[m][n] = sum_k A(m,k) B(n,k) (+ bias[n]) (set to zero where mask[m][n] <= 0: the backward of a relu on the input)
  * bf16 operands, fp32 accumulate/output.  a_col = 0: A is stored [M][lda] (k contiguous); 1: stored [K][lda] (m

@@ -61,7 +61,6 @@ _SIGS = {
     "scp_spmm_dw_bf16_g16": (I, [I, I, I, P, P, P, P, P, L, P, L, P]),
     "scp_spmm_dw_adamw_bf16": (I, [I, I, I, P, P, P, P, P, L, P, L, P, P, P, L, F, F, F, F, F, F, F, F, P, P]),
     "scp_gemm_nt": (I, [I, I, I, P, L, L, P, L, L, P, L, P, I, I, I, P]),
-    "scp_gemm_lib_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P]),
     "scp_gemm_bf16_nsplit": (I, [I, I, I]),
     "scp_gemm_bf16_ws_floats": (L, [I, I, I, L]),
     "scp_gemm_bf16": (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, L, P, P]),

@@ -345,18 +345,21 @@ __global__ __launch_bounds__(64 * NW) void wgemm_kernel(WgArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int mb = m0 + wm * 128 + 32 * i + 4 * (lane >> 5);
-        const unsigned cbase = (unsigned)(((long)mb * g.ldc + n) * 4) | colbad;
-        const unsigned mbase = (unsigned)(((long)mb * g.ldm + n) * 2) | colbad;
 #pragma unroll
         for (int e = 0; e < 16; e++) {
           const int r = (e & 3) + 8 * (e >> 2);
+          // The out-of-range mark REPLACES the offset (a top bit OR-ed into a base would be carried out again by the
+          // row term when C ends just below 2 GiB); offsets are formed in 64 bits and compared with the extent.
+          const long co = ((long)(mb + r) * g.ldc + n) * 4, mo = ((long)(mb + r) * g.ldm + n) * 2;
+          const unsigned coff = (colbad || co >= (long)g.c_bytes) ? OOR : (unsigned)co;
           float v = acc[i][j][e] + bn;
           if (DIRECT && g.mask) {
-            const unsigned short mk = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsM, (int)(mbase + (unsigned)(r * g.ldm * 2)), 0, 0);
+            const unsigned moff = (colbad || mo >= (long)g.m_bytes) ? OOR : (unsigned)mo;
+            const unsigned short mk = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsM, (int)moff, 0, 0);
             const float mf = __uint_as_float((unsigned)mk << 16);
             if (!(mf > 0.f)) v = 0.f;
           }
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, (int)(cbase + (unsigned)(r * g.ldc * 4)), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, (int)coff, 0, 0);
         }
       }
     }
@@ -493,8 +496,8 @@ extern "C" int scp_gemm_bf16_adamw(int M, int N, int K, const void* A, long lda,
             "scp_gemm_bf16_adamw: leading dimension too small");
   SCP_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, SCP_ERR_ARG,
             "scp_gemm_bf16_adamw: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
-  SCP_CHECK((long)K * lda * 2 < (1L << 31) && (long)K * ldb * 2 < (1L << 31), SCP_ERR_SHAPE,
-            "scp_gemm_bf16_adamw: an operand of 2 GiB or more is not supported");
+  SCP_CHECK(((long)K + 3 * TK) * lda * 2 + 4096 < (1L << 31) && ((long)K + 3 * TK) * ldb * 2 + 4096 < (1L << 31), SCP_ERR_SHAPE,
+            "scp_gemm_bf16_adamw: an operand within 3 K-steps of 2 GiB (or larger) is not supported (see scp_gemm_bf16)");
   SCP_CHECK(N % 4 == 0 && ldw % 4 == 0 && ld_bf16 % 4 == 0 &&
                 (((uintptr_t)W | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) == 0 && ((uintptr_t)W_bf16 % 8) == 0,
             SCP_ERR_SHAPE, "scp_gemm_bf16_adamw: needs N %% 4 == 0, leading dimensions %% 4 == 0 and 16-byte aligned W / moments");
@@ -539,8 +542,12 @@ extern "C" int scp_gemm_bf16(int a_col, int b_col, int M, int N, int K, const vo
             "scp_gemm_bf16: leading dimension too small (operands are padded to a multiple of 8 columns)");
   SCP_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, SCP_ERR_ARG,
             "scp_gemm_bf16: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
-  SCP_CHECK(a_rows * lda * 2 < (1L << 31) && b_rows * ldb * 2 < (1L << 31), SCP_ERR_SHAPE,
-            "scp_gemm_bf16: an operand of 2 GiB or more is not supported");
+  // The K loop marks dead loads by OR-ing the top offset bit into the per-step term and then adds the per-chunk offset:
+  // the sum must stay below 2^31 for every (step <= last + 2, chunk), or the mark would be carried out and real data
+  // read.  Hence the slack of two K-steps (k-major operand: whole k rows) on top of the operand's own extent.
+  SCP_CHECK((a_rows + (a_col ? 3 * TK : 0)) * lda * 2 + 4096 < (1L << 31) &&
+                (b_rows + (b_col ? 3 * TK : 0)) * ldb * 2 + 4096 < (1L << 31), SCP_ERR_SHAPE,
+            "scp_gemm_bf16: an operand within 3 K-steps of 2 GiB (or larger) is not supported");
   SCP_CHECK(!mask || ldm >= N, SCP_ERR_ARG, "scp_gemm_bf16: mask leading dimension too small");
   WgArgs g = {};
   g.A = (const __bf16*)A;

@@ -66,7 +66,7 @@ class GradSync:
         loss carries in the global-batch loss.  A device scalar."""
         nv = torch.as_tensor(n_valid, dtype=torch.float64, device=device).reshape(1).clone()
         tot = self._sum(nv.clone())
-        return (nv / tot).to(torch.float32).reshape(())
+        return (nv / torch.clamp(tot, min=1.0)).to(torch.float32).reshape(())      # no valid label anywhere: shares 0
 
     def broadcast(self, tensors, src=0):
         for t in tensors:
@@ -138,7 +138,7 @@ class GradSync:
         dev = params[0].device
         nv = torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(1).clone()
         tot = self._sum(nv.clone())
-        w = (nv / tot).to(torch.float32)
+        w = (nv / torch.clamp(tot, min=1.0)).to(torch.float32)
         grads = [p.grad for p in params if p.grad is not None]
         if grads:
             torch._foreach_mul_(grads, w.reshape(()))
@@ -181,7 +181,7 @@ class GradSync:
         nv = torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(())
         lv = torch.zeros((), dtype=torch.float64, device=dev) if loss is None else loss.detach().double().reshape(())
         v = self._sum(torch.stack([nv, lv * nv]))
-        w = (nv / v[0]).to(torch.float32)
+        w = (nv / torch.clamp(v[0], min=1.0)).to(torch.float32)
         if some_rank_empty:
             self._align_grads(params, sink)
         grads = [p.grad for p in params if p.grad is not None]
@@ -191,7 +191,7 @@ class GradSync:
             sink[0].mul_(w.to(sink[0].dtype))      # exact for equal shards on 2^k ranks (w = 1 / world)
         self.start_all_reduce(grads, sink=sink)
         self.finish()
-        return (v[1] / v[0]).to(torch.float32)
+        return (v[1] / torch.clamp(v[0], min=1.0)).to(torch.float32)
 
     def weighted_mean(self, value, n_valid):
         dev = value.device

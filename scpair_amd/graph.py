@@ -14,6 +14,10 @@ What makes the step capturable:
   * by-value kernel arguments that change per step are replaced by device words (seed_dev / bc_dev arguments).
 The arithmetic and the kernel order are those of the eager step, so with dropout off a replayed step is bitwise the
 eager step.  Single-process training only (a gradient exchange between backward and the optimiser step stays eager).
+
+EXPERIMENTAL, and not reachable from scPair_object or bench.py unless SCPAIR_EXPERIMENTAL_GRAPH=1 is set: bitwise-tested
+at small shapes only.  The replay of the full-size (C2) step ended with an unresponsive GPU box twice in round 2 and
+the cause was never isolated, so nothing here is offered as a supported path.
 """
 from __future__ import annotations
 
@@ -79,9 +83,13 @@ class CapturedStep:
         if rows.shape != self.rows.shape:
             raise ValueError(f"CapturedStep: captured for {tuple(self.rows.shape)} row ids, got {tuple(rows.shape)}")
         self.rows.copy_(rows, non_blocking=True)
-        bc1 = bc2 = 1.0
-        for o in self.opts:
-            bc1, bc2 = o.dyn_advance()
+        # every optimiser advances; the bias corrections come from those that own captured parameters (one that updated
+        # nothing returns (1, 1)) and must agree: the replay's kernels all read the same two device words
+        pairs = [o.dyn_advance() for o in self.opts]
+        live = {(float(a), float(b)) for a, b in pairs if (a, b) != (1.0, 1.0)}
+        if len(live) > 1:
+            raise RuntimeError(f"CapturedStep: the optimisers of one captured step disagree on AdamW's bias corrections {sorted(live)}")
+        bc1, bc2 = live.pop() if live else (1.0, 1.0)
         self.replays += 1
         self.state.set(self.replays * self.seed_stride, bc1, bc2)
         self.graph.replay()

@@ -362,6 +362,9 @@ class _GraphStepper:
     def step(self, rows, rows_dev):
         if rows.min() < 0 or rows.max() >= self.xtr.n_rows:
             raise IndexError("minibatch row id out of range")
+        if len(np.unique(rows)) != len(rows):
+            # the fixed tile-list capacity (max_batch_nnz) bounds minibatches of DISTINCT rows only
+            raise ValueError("a captured step needs distinct row ids in a minibatch")
         if self.cs is None:
             from .graph import CapturedStep
             self.cap_x, self.cap_y = self.xtr.max_batch_nnz(self.B), self.ytr.max_batch_nnz(self.B)
@@ -476,6 +479,9 @@ class scPair_object():
         self.fuse_optimizer = fuse_optimizer  # AdamW step of the first-layer weights inside their dW kernel (1 process)
         # opt-in, single process: full-size minibatch steps are recorded once per direction as a HIP graph and
         # replayed (scpair_amd.graph.CapturedStep; same kernels in the same order, so results do not change)
+        if capture_step and not os.environ.get("SCPAIR_EXPERIMENTAL_GRAPH"):
+            raise ValueError("capture_step=True is experimental (bitwise-tested at small shapes only; the full-size replay is "
+                             "not trusted, DESIGN.md section 7): set SCPAIR_EXPERIMENTAL_GRAPH=1 to use it anyway")
         self.capture_step = capture_step
         # Opt-in input pre-transform per modality, e.g. {'Gene Expression': 'log1p_norm'} or {'Gene Expression':
         # ('log1p_norm', 1e4)}: applied to encoder inputs only, on the fly in the minibatch tile list.  The reference

@@ -204,11 +204,6 @@ def cast_bf16(x, rows, cols, relu=False):
     return out
 
 
-def gemm_lib(ta, tb, m, n, k, A, lda, B, ldb, C, ldc):
-    _lib.check(_lib.lib().scp_gemm_lib_bf16(ta, tb, m, n, k, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc,
-                                            _lib.stream()), "scp_gemm_lib_bf16")
-
-
 def gemm_bf16(a_col, b_col, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldm=0):
     """C[m][n] = sum_k A(m,k) B(n,k) (+ bias[n]) (zero where mask <= 0) on the hand-written wide MFMA kernel
     (csrc/wgemm.hip); A / B bf16, stored [rows][ld] (col flag 0) or [K][ld] (col flag 1); C fp32 [M][ldc]."""
@@ -930,7 +925,12 @@ class SyncBatchNormFn(torch.autograd.Function):
             raise RuntimeError("synchronised BatchNorm backward needs this rank's loss share: call "
                                "ops.set_bn_sync_weight(GradSync.share_of(n_valid, device)) before backward()")
         S = ctx.sync._sum(torch.cat([db, dg]) * w)
-        coef = rstd / (N * w) if gamma is None else gamma * rstd / (N * w)
+        # A rank whose shard holds rows but no valid label element has share w = 0: its gradients are multiplied by 0 in
+        # the exchange anyway, so the mean terms are dropped there instead of dividing by zero (0 * NaN would poison
+        # the all-reduced gradients of every rank).  The gradient the other ranks' losses send through this rank's rows
+        # of the global statistics is lost in that (degenerate) step.
+        inv = torch.where(w > 0, 1.0 / (N * torch.clamp(w, min=1e-30)), torch.zeros_like(N * w))
+        coef = rstd * inv if gamma is None else gamma * rstd * inv
         xhat = (x - mean) * rstd
         dx -= coef * (S[:H] + xhat * S[H:])
         if gamma is None:

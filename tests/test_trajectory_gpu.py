@@ -50,9 +50,14 @@ def _run(name, precision, **kw):
     return d, c, obj
 
 
-def test_trajectory_with_captured_steps_is_bitwise_the_eager_one():
-    """scPair_object(capture_step=True): full-size minibatch steps replayed from a HIP graph, the ragged last batch of
+def test_trajectory_with_captured_steps_is_bitwise_the_eager_one(monkeypatch):
+    """(experimental path: refused unless SCPAIR_EXPERIMENTAL_GRAPH is set, which is checked first)
+    scPair_object(capture_step=True): full-size minibatch steps replayed from a HIP graph, the ragged last batch of
     each epoch eager -- the same training and validation losses, bit for bit, as the all-eager run."""
+    monkeypatch.delenv("SCPAIR_EXPERIMENTAL_GRAPH", raising=False)
+    with pytest.raises(ValueError):
+        S.scPair_object(None, cov=None, device=DEV, save_model=False, capture_step=True)
+    monkeypatch.setenv("SCPAIR_EXPERIMENTAL_GRAPH", "1")
     _, c, eager = _run("traj_nb_ber_bn", "fp32")
     _, _, graph = _run("traj_nb_ber_bn", "fp32", capture_step=True)
     for k in eager.history:

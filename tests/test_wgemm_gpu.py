@@ -103,3 +103,27 @@ def test_wide_gemm_output_of_two_gib_and_more():
     ops.gemm_bf16(0, 0, M, N, K, A, K, B, K, C2, N)          # no mask: interior tiles plain stores, edge tiles guarded
     want = A.float() @ B.float().t()
     assert float((C2 - want).abs().max()) <= 2e-5 * 8 * 16.0
+
+
+def test_wide_gemm_output_just_below_two_gib():
+    """C ends 1.1 MB below 2^31 with ragged M and N: the corner tile's rows straddle M and its columns run past N.  An
+    out-of-range mark OR-ed into a 32-bit base offset would be carried out again by the row term there and the dropped
+    stores would land in the first rows of C instead (26 830 x 20 000 fp32 = 2 146 400 000 bytes)."""
+    from scpair_amd import ops
+    dev = torch.device("cuda:0")
+    M, N, K = 26830, 20000, 64
+    assert (1 << 31) - 28 * N * 4 < M * N * 4 < (1 << 31)
+    gen = torch.Generator(device=dev).manual_seed(12)
+    A = torch.randn((M, K), device=dev, generator=gen).to(torch.bfloat16)
+    B = torch.randn((N, K), device=dev, generator=gen).to(torch.bfloat16)
+    bias = torch.randn((N,), device=dev, generator=gen)
+    for with_mask in (False, True):
+        mask = (torch.randn((M, N), device=dev, generator=gen) - 0.3).to(torch.bfloat16) if with_mask else None
+        C = torch.full((M, N), 7.0, device=dev)
+        ops.gemm_bf16(0, 0, M, N, K, A, K, B, K, C, N, bias=bias, mask=mask, ldm=N if with_mask else 0)
+        want = A.float() @ B.float().t() + bias
+        if with_mask:
+            want = torch.where(mask.float() > 0, want, torch.zeros_like(want))
+        assert float((C[:64] - want[:64]).abs().max()) <= 2e-5 * 8 * 16.0, "the first rows of C were overwritten"
+        assert float((C - want).abs().max()) <= 2e-5 * 8 * 16.0
+        del want, C, mask
