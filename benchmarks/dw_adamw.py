@@ -37,5 +37,5 @@ for mode in ("plain", "fused"):
     e1.record(); torch.cuda.synchronize()
     ops.set_fused_timer(None)
     if tm:
-        print(f"   fused dW+AdamW kernel alone: {sum(a.elapsed_time(b) for a, b, _, _ in tm) / len(tm) * 1e3:.1f} us (B={B})")
+        print(f"   fused dW+AdamW kernel alone: {sum(a.elapsed_time(b) for a, b, *_ in tm) / len(tm) * 1e3:.1f} us (B={B})")
     print(f"{which} {mode} stagger={os.environ.get('SCP_DW_STAGGER', '0')}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per fwd+bwd+opt step")

@@ -35,9 +35,10 @@ def _ns():
 
 
 def set_fused_timer(sink):
-    """Diagnostic: a list that receives (start_event, end_event, n_params, operand_bytes) for every fused
-    weight-gradient + AdamW launch (bench.py's roofline figure), or None to switch it off.  operand_bytes = the
-    tile-list entries and the bf16 dY^T the launch reads."""
+    """Diagnostic: a list that receives (start_event, end_event, n_params, operand_bytes, kind) for every fused
+    weight-gradient + AdamW launch (bench.py's roofline figure), or None to switch it off.  kind "spmm_dw_adamw": the
+    sparse first layers (operand_bytes = the tile-list entries and the bf16 dY^T the launch reads); "wgemm_adamw": a wide
+    plain layer (operand_bytes = the bf16 dy and x operands)."""
     _cfg["fused_timer"] = sink
 
 
@@ -265,9 +266,16 @@ class LinearFn(torch.autograd.Function):
                 # weight gradient + AdamW step of W in one kernel (after dx, which reads the shadow this rewrites):
                 # dW never reaches HBM, autograd gets no gradient for W
                 m_, v_, sh_, hp = ctx.fused.begin_step(W)
+                tm = _cfg["fused_timer"]
+                if tm is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 _lib.check(_lib.lib().scp_gemm_bf16_adamw(N, K, M, dyb.data_ptr(), dyb.shape[1], xb.data_ptr(), xb.shape[1],
                                                           W.data_ptr(), K, m_.data_ptr(), v_.data_ptr(), sh_.data_ptr(),
                                                           sh_.shape[1], *hp, _lib.stream()), "scp_gemm_bf16_adamw")
+                if tm is not None:
+                    e1.record()
+                    tm.append((e0, e1, N * K, 2 * M * (dyb.shape[1] + xb.shape[1]), "wgemm_adamw"))
             elif ctx.needs_input_grad[1]:
                 dW = _empty((N, K), dy)
                 # dW[n][j] = sum_m dy[m][n] x[m][j]: both operands k-major
@@ -404,7 +412,7 @@ class FcnnLayerFn(torch.autograd.Function):
                                                         _lib.stream()), "scp_spmm_dw_adamw_bf16")
                     if tm is not None:
                         e1.record()
-                        tm.append((e0, e1, H * Ftot, int(t.nnz) * (8 if t.val is not None else 4) + 2 * H * ldt))
+                        tm.append((e0, e1, H * Ftot, int(t.nnz) * (8 if t.val is not None else 4) + 2 * H * ldt, "spmm_dw_adamw"))
                 elif ctx.sink is not None:
                     # data parallel: dW goes to the exchange buffer as bf16; the optimiser reads it from there
                     dW = None
@@ -733,7 +741,7 @@ class EncBranchesFn(torch.autograd.Function):
                                                             *hp, stream), "scp_spmm_dw_adamw_bf16")
                         if tm is not None:
                             e1.record()
-                            tm.append((e0, e1, Hu * F, int(t.nnz) * (8 if t.val is not None else 4) + 2 * Hu * ldt))
+                            tm.append((e0, e1, Hu * F, int(t.nnz) * (8 if t.val is not None else 4) + 2 * Hu * ldt, "spmm_dw_adamw"))
                     elif sk is not None:
                         _lib.check(L.scp_spmm_dw_bf16_g16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, sk.view.data_ptr(), F, stream),
                                    "scp_spmm_dw_bf16_g16")

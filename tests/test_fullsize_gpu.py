@@ -239,3 +239,153 @@ def test_wide_linear_c3_shape_against_dense_matmuls():
         assert torch.equal(ops.shadow_of(W, create=False)[:, :G], W.detach().bfloat16())
     finally:
         S.set_precision("fp32")
+
+
+def _nb_dense(h, W, b, L, Y, rnd):
+    """Output_Module_Raw.forward without zero inflation + raw_loss('nb') (model.py:229-259, loss.py:46-48,
+    scVI_distribution.py:74-105) as dense torch math; `rnd` rounds the MFMA operands (bf16 mode)."""
+    from oracle import ref_cpu as O
+    hq = h + (rnd(h.detach()) - h.detach())
+    Wq = W + (rnd(W.detach()) - W.detach())
+    a = torch.relu(hq @ Wq.t() + b)
+    rate = L.reshape(-1, 1) * torch.softmax(a, -1)
+    return -(O.log_nb(Y, rate, torch.exp(a)).double().mean()).float()
+
+
+@pytest.mark.parametrize("prec,B", [("fp32", 1024), ("bf16", 1024), ("bf16", 4096)])
+def test_nb_decoder_c2_shape(prec, B):
+    """The fused NB decoder (dec_kernel<..., NB_STATS / LOSS / GRAD>: three passes, 79 feature tiles, row reductions
+    across the chunks) at the size bench.py runs it: G = 20 000 genes, K = 40, batch 1024 (C2) and 4096 (C5).  Loss and
+    dh / dW / db against the dense formula on the device (autograd, reductions in fp64); at batch 1024 also against the
+    CPU oracle's output_raw + raw_loss.  Tolerances: fp32 mode loss 2e-5 relative, gradients 5e-4 of their scale; bf16
+    mode (operands rounded once, hardware exp / log / rcp in the epilogue) 2e-3 / 2e-2."""
+    import scpair_amd as S
+    from scpair_amd import ops, synth
+    from oracle import ref_cpu as O
+    S.set_precision(prec)
+    try:
+        G, K = 20_000, 40
+        rna = synth.make_rna_device(2 * B, G, DEV, seed=21, target_density=0.10)
+        rows = np.random.default_rng(6).permutation(2 * B)[:B]
+        t = S.BatchTiles(rna, rows, want_lib=True)
+        g_ = torch.Generator(device=DEV).manual_seed(4)
+        h = torch.randn(B, K, device=DEV, generator=g_).requires_grad_(True)
+        W = (torch.randn(G, K, device=DEV, generator=g_) * 0.15).requires_grad_(True)
+        b = (torch.randn(G, device=DEV, generator=g_) * 0.2).requires_grad_(True)
+        loss = ops.nb_decoder_loss(h, W, b, None, None, t.lib, None, t)
+        gh, gW, gb = torch.autograd.grad(loss, (h, W, b))
+        rnd = (lambda x: x.bfloat16().float()) if prec == "bf16" else (lambda x: x)
+        hr, Wr, br = (x.detach().clone().requires_grad_(True) for x in (h, W, b))
+        Y = t.to_dense()
+        ref = _nb_dense(hr, Wr, br, t.lib, Y, rnd)
+        rh, rW, rb = torch.autograd.grad(ref, (hr, Wr, br))
+        lt, gt_ = (2e-5, 5e-4) if prec == "fp32" else (2e-3, 2e-2)
+        print(f"[measured] nb decoder {prec} B={B}: loss rel {abs(float(loss) - float(ref)) / abs(float(ref)):.2e}, "
+              f"dh {_scale_err(gh, rh):.2e} dW {_scale_err(gW, rW):.2e} db {_scale_err(gb, rb):.2e}", flush=True)
+        assert abs(float(loss) - float(ref)) < lt * abs(float(ref)), (float(loss), float(ref))
+        for nm, a_, r_ in (("dh", gh, rh), ("dW", gW, rW), ("db", gb, rb)):
+            assert _scale_err(a_, r_) < gt_, (nm, _scale_err(a_, r_))
+        with torch.no_grad():
+            le = ops.nb_decoder_loss(h, W, b, None, None, t.lib, None, t)
+        assert abs(float(le) - float(loss)) <= 1e-6 * abs(float(loss))
+        if B == 1024 and prec == "fp32":
+            sd = {"output_mean.0.weight": W.detach().cpu(), "output_mean.0.bias": b.detach().cpu()}
+            if prec == "fp32":
+                _, theta, rate, _ = O.output_raw(sd, h.detach().cpu(), None, t.lib.reshape(-1, 1).cpu(), None, True, "feature-cell")
+                want = float(O.raw_loss(Y.cpu(), rate, theta, None, "nb"))
+                assert abs(float(loss) - want) < 1e-4 * abs(want), (float(loss), want)
+    finally:
+        S.set_precision("fp32")
+
+
+def _paired_models(S, G, P, hidden, zinb, dev):
+    from torch import nn
+    out = []
+    for in_dim, out_dim, dist_, infer in ((G, P, "ber", True), (P, G, "zinb" if zinb else "nb", False)):
+        S.set_seed(0)
+        enc = S.Input_Module(input_dim=in_dim, input_batch_num=0, hidden_layer=hidden, activation=nn.LeakyReLU(), layernorm=True,
+                             batchnorm=False, dropout_rate=0.0, add_linear_layer=True, infer_library_size=infer)
+        S.set_seed(0)
+        if dist_ == "ber":
+            dec = S.Output_Module_Ber(output_dim=out_dim, output_batch_num=0, hidden_layer=hidden, infer_library_size=True,
+                                      sample_factor=False, feature_factor=False)
+        else:
+            dec = S.Output_Module_Raw(output_dim=out_dim, output_batch_num=0, hidden_layer=hidden, infer_library_size=False,
+                                      sample_factor=True, feature_factor=False, zero_inflated=zinb, dispersion="feature-cell")
+        enc.apply(S.init_weights); dec.apply(S.init_weights)
+        out.append((enc, dec, dist_))
+    return out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("prec,zinb", [("fp32", False), ("bf16", False), ("bf16", True)])
+def test_whole_paired_step_c2_shape_vs_oracle(prec, zinb):
+    """ONE whole paired training step at the bench's shapes -- 20 000 genes, 100 000 peaks, hidden [900, 40], batch 1024,
+    dropout 0 -- assembled exactly as bench.py / scPair_object assemble it (packed 1800-row first layer, fused encoder
+    tails, fused decoders, AdamW of the wide weights inside their weight-gradient kernels in bf16 mode; zinb: the G x G
+    zero-inflation layer live, its AdamW step in the GEMM epilogue) against oracle.Direction.train_step from the same
+    weights on the same batch (model.py:229-259, utils.py:118-148).  Stated: loss rel 1e-5 (fp32) / 2e-2 (bf16); after the
+    step at least 99 % of the entries of every updated tensor within 2e-3 x lr of the oracle's and none further than
+    0.1 lr (fp32; measured 99.8 %, 0.043 lr on the 900 x 100 000 layer), at least 99 % of the entries of the first-layer /
+    wide weights within 0.2 x lr and none further than 2 lr in bf16 mode (Adam's
+    first step is lr * g / (|g| + eps): an entry whose gradient is within rounding of zero can land anywhere in
+    [-lr, lr]); the second step's loss again within the loss bound."""
+    import scpair_amd as S
+    from scpair_amd import synth
+    from scpair_amd.utils import _predictor_loss
+    from oracle import ref_cpu as O
+    S.set_precision(prec)
+    try:
+        G, P, B, hidden, lr = 20_000, 100_000, 1024, [900, 40], 1e-3
+        rna = synth.make_rna_device(2 * B, G, DEV, seed=31, target_density=0.10)
+        atac = synth.make_atac_device(2 * B, P, DEV, seed=32, p=0.03)
+        rows = np.sort(np.random.default_rng(8).permutation(2 * B)[:B])
+        t_rna, t_atac = S.BatchTiles(rna, rows, want_lib=True), S.BatchTiles(atac, rows, want_lib=False)
+        xr, xa = t_rna.to_dense().cpu(), t_atac.to_dense().cpu()
+        ltol = 1e-5 if prec == "fp32" else 2e-2
+        torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+        for (enc, dec, dist_), (tx, ty, xin, xout) in zip(_paired_models(S, G, P, hidden, zinb, DEV),
+                                                         ((t_rna, t_atac, xr, xa), (t_atac, t_rna, xa, xr))):
+            cpu_sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()
+                                if not k.startswith("output_inverse_dispersion")}
+            ref = O.Direction(cpu_sd(enc), cpu_sd(dec), dist_, dict(sample_factor=(dist_ != "ber"), lr=lr))
+            enc.to(DEV).train(); dec.to(DEV).train()
+            de, ne, _, _ = S.add_weight_decay(enc, output_layer=["output"])
+            dd, nd, _, _ = S.add_weight_decay(dec, output_layer=["output"])
+            opt = S.FusedAdamW([g for g in ({"params": de, "weight_decay": 1e-9, "lr": lr}, {"params": dd, "weight_decay": 1e-9, "lr": lr},
+                                            {"params": ne, "weight_decay": 0, "lr": lr}, {"params": nd, "weight_decay": 0, "lr": lr})
+                                if g["params"]])
+            if prec == "bf16":
+                firsts = [enc.hidden_rep[0].weight] + ([enc.hidden_lib[0][0].weight] if dist_ == "ber" else [])
+                opt.fuse_first_layer(*firsts)
+                if dist_ == "zinb":
+                    opt.fuse_weight_update(dec.output_dropout.weight)
+            lib_dev = ty.lib.reshape(-1, 1) if dist_ != "ber" else None
+            lib_cpu = xout.sum(1, keepdim=True) if dist_ != "ber" else None
+            got, want = [], []
+            for _ in range(2):
+                loss = _predictor_loss(tx, ty, lib_dev, enc, dec, dist_, False, None, None)
+                opt.zero_grad()
+                S.ops.backward_root(loss)
+                opt.step(release_grads=True)
+                got.append(float(loss))
+                want.append(ref.train_step(xin, xout, lib_cpu))
+                if len(got) == 1:
+                    # after ONE step from identical weights
+                    for tag, mod, sd in (("enc", enc, ref.enc), ("dec", dec, ref.dec)):
+                        for k, v in mod.state_dict().items():
+                            if k not in sd or not v.dtype.is_floating_point:
+                                continue
+                            d_ = (v.detach().cpu() - sd[k].detach()).abs()
+                            if prec == "fp32":
+                                frac = float((d_ < 2e-3 * lr + 1e-7).float().mean())
+                                assert frac > 0.99 and float(d_.max()) <= 0.1 * lr, (dist_, tag, k, frac, float(d_.max()) / lr)
+                            elif v.ndim == 2 and v.numel() > 1_000_000:
+                                frac = float((d_ < 0.2 * lr).float().mean())
+                                assert frac > 0.99 and float(d_.max()) <= 2.001 * lr, (dist_, tag, k, frac, float(d_.max()) / lr)
+            err = max(abs(g - w) / abs(w) for g, w in zip(got, want))
+            print(f"[measured] whole step {prec} zinb={zinb} {dist_}: losses {got} vs oracle {want} (max rel {err:.2e})", flush=True)
+            assert err < ltol, (dist_, got, want)
+            del ref, enc, dec, opt
+    finally:
+        S.set_precision("fp32")
