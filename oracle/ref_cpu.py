@@ -424,8 +424,10 @@ class Direction:
 
 
 def run_direction(direction: Direction, xtr, ytr, libtr, xva, yva, libva, batches, n_epochs,
-                  covtr=None, covva=None, patience=25):
-    """model.py:727-799 epoch loop with replayed batches (list of row-index arrays, in order)."""
+                  covtr=None, covva=None, patience=25, step_lr=None):
+    """model.py:727-799 epoch loop with replayed batches (list of row-index arrays, in order).  step_lr = (step, gamma):
+    the 'StepLR' scheduler of model.py:596-597, stepped once per epoch after validation while lr > 1e-7 (model.py:783-784)."""
+    lr0 = direction.opt.lr
     per_epoch = len(batches) // n_epochs
     train_losses, val_losses = [], []
     best, best_sd, no_imp = float("inf"), None, 0
@@ -438,6 +440,8 @@ def run_direction(direction: Direction, xtr, ytr, libtr, xva, yva, libva, batche
                 None if covtr is None else covtr[rows]))
         v = direction.eval_loss(xva, yva, libva, covva)
         val_losses.append(v)
+        if step_lr is not None and direction.opt.lr > 1e-7:
+            direction.opt.lr = lr0 * step_lr[1] ** ((ep + 1) // step_lr[0])
         if v < best:
             best, no_imp, best_sd = v, 0, direction.snapshot()
         else:

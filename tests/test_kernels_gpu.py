@@ -118,6 +118,7 @@ def test_linear_autograd(S, M, K, N):
 
 
 @pytest.mark.parametrize("B,F,H,C,ln,p_sparse", [(130, 333, 16, 0, True, True), (257, 2051, 900, 3, True, True),
+                                                 (200, 1500, 132, 0, True, True),
                                                  (64, 64, 8, 0, False, True), (100, 50, 40, 4, True, False)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_fcnn_layer(S, B, F, H, C, ln, p_sparse, prec):
@@ -723,7 +724,8 @@ def test_foscttm_fosfttm_gpu(S):
     assert abs(E.FOSCTTM(x, y) - av) < 2e-6       # fp32 summation order can flip a handful of near-ties in 1e6 pairs
 
 
-@pytest.mark.parametrize("B,F,H,binary", [(300, 1000, 72, False), (1024, 4100, 200, True), (64, 256, 128, False)])
+@pytest.mark.parametrize("B,F,H,binary", [(300, 1000, 72, False), (1024, 4100, 200, True), (64, 256, 128, False),
+                                          (300, 1000, 132, False), (2200, 900, 264, True)])
 def test_first_layer_wgrad_with_adamw_epilogue(S, B, F, H, binary):
     """scp_spmm_dw_adamw_bf16 (weight gradient + AdamW step in one kernel) against the two-kernel path
     (scp_spmm_dw_bf16 then scp_adamw_multi) over three steps: weights, both moments and the bf16 shadow."""
@@ -857,7 +859,7 @@ def test_vae_decoder_fused_loss_vs_oracle(S, lik, libmode):
     close(lg, lo, rtol=5e-5, atol=0, what="generic path")
 
 
-@pytest.mark.parametrize("B,F,H,binary", [(300, 1000, 72, False), (512, 4100, 200, True)])
+@pytest.mark.parametrize("B,F,H,binary", [(300, 1000, 72, False), (512, 4100, 200, True), (300, 1000, 132, True)])
 def test_first_layer_wgrad_into_bf16_exchange_buffer(S, B, F, H, binary):
     """Data-parallel path in precision 'bf16': scp_spmm_dw_bf16_g16 writes dW as bf16 into the exchange buffer and
     scp_adamw_multi reads it from there (g_bf16) — against the fp32-gradient path with the gradient rounded to bf16
@@ -899,5 +901,38 @@ def test_first_layer_wgrad_into_bf16_exchange_buffer(S, B, F, H, binary):
             ops.set_grad_sink(W, None)
         for nm, a, r_ in zip(("W", "exp_avg", "exp_avg_sq"), res["sink"], res["plain"]):
             assert float((a - r_).abs().max()) <= 1e-6 * float(r_.abs().max()) + 1e-12, nm
+    finally:
+        ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("B,F,H,binary", [(300, 1001, 132, False), (2200, 900, 264, True), (130, 515, 900, False)])
+def test_first_layer_wgrad_tail_rows(S, B, F, H, binary):
+    """Hidden widths of the form 128 k + r, r <= 8 (the reference's default 900 = 7 x 128 + 4): the last 128-row tile of
+    the MFMA weight-gradient kernels is almost empty.  Every row of dW against the fp32 matmul of the bf16-rounded
+    operands (the products are exact in fp32; 2e-5 of the scale is stated for the summation order), the last rows
+    separately, and the result is bitwise reproducible.  (A variant that gave those rows to a vector-unit kernel and
+    the MFMA launch only the full tiles passed this test and measured slower, 487 + 32 us against 502 us at C2: the
+    launch is bound by the HBM stream of its epilogues, which the nearly empty tiles do not add to.)"""
+    ops = S.ops
+    ops.set_precision("bf16")
+    try:
+        rng = np.random.default_rng(H)
+        x = rand_csr(rng, B, F, 0.08, binary=binary)
+        tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(x, S.dev, binary=binary), np.arange(B))
+        X = tiles.to_dense().bfloat16().float()
+        g = torch.Generator(device=S.dev).manual_seed(H)
+        W = (torch.randn(H, F, device=S.dev, generator=g) * 0.05).requires_grad_(True)
+        dY = torch.randn(B, H, device=S.dev, generator=g)
+        out = ops.fcnn_layer(tiles, None, W, None, None, None, 1.0)
+        (g1,) = torch.autograd.grad(out, W, dY, retain_graph=True)
+        (g2,) = torch.autograd.grad(out, W, dY)
+        ref = dY.bfloat16().float().t() @ X
+        err = float((g1 - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-5, err
+        tail = H % 128
+        assert 0 < tail <= 8
+        errt = float((g1[H - tail:] - ref[H - tail:]).abs().max()) / float(ref.abs().max())
+        assert errt < 2e-5, errt
+        assert torch.equal(g1, g2)
     finally:
         ops.set_precision("fp32")

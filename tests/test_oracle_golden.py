@@ -243,8 +243,11 @@ def _traj_data(c):
     return data, dense
 
 
-@pytest.mark.parametrize("name", ["traj_zinb_ber", "traj_nb_ber", "traj_nb_ber_bn", "traj_nb_ber_cov"])
+@pytest.mark.parametrize("name", ["traj_zinb_ber", "traj_nb_ber", "traj_nb_ber_bn", "traj_nb_ber_cov", "traj_earlystop",
+                                  "traj_steplr"])
 def test_training_trajectory(name):
+    """traj_earlystop / traj_steplr: the epoch-control branches (early stopping that fires with patience 2: the oracle
+    must stop after the same epoch and return the same best-epoch weights; the StepLR scheduler across its first decay)."""
     d = U.load(name)
     c = U.cfg(d, "cfg")
     data, dense = _traj_data(c)
@@ -259,10 +262,15 @@ def test_training_trajectory(name):
         libtr = ytr.sum(1, keepdim=True) if use_lib else None
         libva = yva.sum(1, keepdim=True) if use_lib else None
         direction = O.Direction(U.sub(d, f"dir{di}/enc_init"), U.sub(d, f"dir{di}/dec_init"), lik,
-                                dict(batchnorm=c["batchnorm"], sample_factor=use_lib))
+                                dict(batchnorm=c["batchnorm"], sample_factor=use_lib, lr=c.get("lr", 1e-3)))
         batches = U.split_batches(d[f"dir{di}/batch_rows"], d[f"dir{di}/batch_sizes"])
+        per_epoch = -(-xtr.shape[0] // c["batch"])
+        # give the loop every epoch the reference was allowed (max_epochs): it has to stop by itself where the reference did
+        batches = batches + [batches[-1]] * (per_epoch * c["epochs"] - len(batches))
         tl, vl, best = O.run_direction(direction, xtr, ytr, libtr, xva, yva, libva, batches, c["epochs"],
-                                       cov["train"], cov["val"])
+                                       cov["train"], cov["val"], patience=c.get("patience", 25),
+                                       step_lr=(25, 0.1) if c.get("scheduler") == "StepLR" else None)
+        assert len(vl) == len(d[f"dir{di}/val_loss"]), "stopped after a different epoch than the reference"
         close(tl, d[f"dir{di}/train_loss"], rtol=2e-4, atol=1e-6)
         close(vl, d[f"dir{di}/val_loss"], rtol=2e-4, atol=1e-6)
         for k, v in U.sub(d, f"dir{di}/enc_final").items():

@@ -42,10 +42,15 @@ def _run(name, precision, **kw):
     d = U.load(name)
     c = U.cfg(d, "cfg")
     tr, va, te = _dicts(c, d)
-    obj = S.scPair_object(None, cov=(["labels"] if c["with_cov"] else None), modalities=c["modalities"], SEED=0,
-                          hidden_layer=c["hidden"], dropout_rate=0.0, batchnorm=c["batchnorm"], layernorm=True,
-                          batch_size=c["batch"], max_epochs=c["epochs"], device=DEV, save_model=False,
-                          zero_inflated=c["zero_inflated"], use_mixed_precision=(precision == "bf16"), verbose=False, **kw)
+    args = dict(cov=(["labels"] if c["with_cov"] else None), modalities=c["modalities"], SEED=0,
+                hidden_layer=c["hidden"], dropout_rate=0.0, batchnorm=c["batchnorm"], layernorm=True,
+                batch_size=c["batch"], max_epochs=c["epochs"], device=DEV, save_model=False,
+                zero_inflated=c["zero_inflated"], use_mixed_precision=(precision == "bf16"), verbose=False)
+    if "patience" in c:        # epoch-control fixtures (tools/make_goldens.py `epoch`)
+        args.update(early_stopping_patience=c["patience"], weight_decay=c["scheduler"],
+                    learning_rate_prediction=c["lr"], mapping_learning_rate=c["lr"])
+    args.update(kw)
+    obj = S.scPair_object(None, **args)
     obj.train_predicting_networks(tr, va, te)
     return d, c, obj
 

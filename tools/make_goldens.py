@@ -526,7 +526,10 @@ def dense_dicts(data, with_cov=False):
 
 
 def gold_trajectory(name, modalities, batchnorm=False, zero_inflated=True, with_cov=False, epochs=6,
-                    n=512, g=64, p=128, hidden=(16, 8), batch=64, seed=0):
+                    n=512, g=64, p=128, hidden=(16, 8), batch=64, seed=0, patience=25, scheduler=None, lr=1e-3,
+                    save_files=False):
+    """patience / scheduler / lr / save_files: the epoch-control branches (model.py:592-602, 783-807): early stopping that
+    fires, the 'StepLR' scheduler, and the files torch.save() leaves behind (names and sizes recorded in cfg)."""
     data = synth.make_paired(n, g, p, seed=seed, p_atac=0.1)
     if with_cov:
         lab = np.random.default_rng(7).integers(0, 4, size=n)
@@ -545,11 +548,15 @@ def gold_trajectory(name, modalities, batchnorm=False, zero_inflated=True, with_
             super().__init__(*a, **k)
     tud.DataLoader = DL      # model.py re-imports DataLoader from torch.utils.data inside the loop
     ref.model.DataLoader = DL
+    import tempfile
+    save_dir = tempfile.mkdtemp(prefix="scpair_gold_") if save_files else None
     try:
         obj = ref.scPair_object(scobj=None, cov=(["labels"] if with_cov else None), modalities=modalities, SEED=0,
                                 hidden_layer=list(hidden), dropout_rate=0.0, batchnorm=batchnorm,
                                 layernorm=True, batch_size=batch, max_epochs=epochs,
-                                device=torch.device("cpu"), save_model=False, zero_inflated=zero_inflated)
+                                device=torch.device("cpu"), save_model=save_files, save_path=save_dir,
+                                zero_inflated=zero_inflated, early_stopping_patience=patience, weight_decay=scheduler,
+                                learning_rate_prediction=lr, mapping_learning_rate=lr)
         enc_d, dec_d = obj.train_predicting_networks(tr, va, te)
         obj.encoder_dict, obj.decoder_dict = enc_d, dec_d
         obj.data_loader_dict_train, obj.data_loader_dict_val, obj.data_loader_dict_test = tr, va, te
@@ -563,9 +570,15 @@ def gold_trajectory(name, modalities, batchnorm=False, zero_inflated=True, with_
         tud.DataLoader = orig_tud_dl
         ref.model.DataLoader = orig_dl
         rec.uninstall()
+    saved = {}
+    if save_files:
+        import shutil
+        saved = {f: os.path.getsize(os.path.join(save_dir, f)) for f in sorted(os.listdir(save_dir))}
+        shutil.rmtree(save_dir)
     out = {"cfg": np.array(json.dumps(dict(modalities=modalities, batchnorm=batchnorm, zero_inflated=zero_inflated,
                                            with_cov=with_cov, epochs=epochs, n=n, g=g, p=p, hidden=list(hidden),
-                                           batch=batch, seed=seed, p_atac=0.1)))}
+                                           batch=batch, seed=seed, p_atac=0.1, patience=patience, scheduler=scheduler,
+                                           lr=lr, saved_files=saved)))}
     if with_cov:
         out["cov"] = data["cov"]
     names = list(modalities.keys())
@@ -670,5 +683,12 @@ if __name__ == "__main__":
         gold_trajectory("traj_nb_ber_cov", {"Gene Expression": "nb", "Peaks": "ber"}, zero_inflated=False,
                         with_cov=True, epochs=3)
         gold_vae_trajectory()
+    if run("epoch"):
+        # epoch control: early stopping that fires (patience 2, lr 0.02: the toy overfits within a few epochs) with the
+        # saved files; and the StepLR scheduler (step 25, gamma 0.1) across its first decay
+        gold_trajectory("traj_earlystop", {"Gene Expression": "nb", "Peaks": "ber"}, zero_inflated=False, epochs=40,
+                        patience=2, lr=2e-2, save_files=True)
+        gold_trajectory("traj_steplr", {"Gene Expression": "nb", "Peaks": "ber"}, zero_inflated=False, epochs=29,
+                        patience=40, scheduler="StepLR", lr=5e-3, n=256, batch=64)
     with open(os.path.join(OUT, "META.json"), "w") as f:
         json.dump(META, f)
