@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 export TMPDIR=/tmp
-timeout -k 10 150 rocprofv3 --kernel-trace -d $ROOT/gpurun_out/kt1 -o r -- python3 bench.py --cpu-steps 0 --steps 6 --warmup 3 --roofline-steps 0 --streams 1 $BENCH_EXTRA > /dev/null 2>&1
+timeout -k 10 150 rocprofv3 --kernel-trace -d $ROOT/gpurun_out/kt1 -o r -- python3 bench.py --cpu-steps 0 --steps 6 --warmup 3 --roofline-steps 0 --streams 1 --no-extras $BENCH_EXTRA > /dev/null 2>&1
 python3 - "$1" <<PY
 import sqlite3, glob, collections, sys
 db = glob.glob("$ROOT/gpurun_out/kt1/**/*.db", recursive=True)[0]

@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 timeout -k 10 400 python3 bench.py > $OUT/prof_bench.json 2> $OUT/prof_bench.err
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --cpu-steps 0 --steps 90 --warmup 5 --roofline-steps 0 --streams 1 > $OUT/prof_streams1.json 2> $OUT/prof_kt.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --cpu-steps 0 --steps 90 --warmup 5 --roofline-steps 0 --streams 1 --no-extras > $OUT/prof_streams1.json 2> $OUT/prof_kt.err
 echo "kernel trace done"
 python3 - <<PY
 import csv, glob, collections, shutil
@@ -36,7 +36,7 @@ with open("$OUT/prof_step_summary.txt", "w") as fh:
 PY
 rm -rf $OUT/kt
 CNT="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"
-timeout -s KILL 240 rocprofv3 --pmc $CNT --output-format csv -d $OUT/pmc -o pmc -- python3 bench.py --cpu-steps 0 --steps 4 --warmup 2 --roofline-steps 0 --streams 1 > /dev/null 2> $OUT/prof_pmc.err
+timeout -s KILL 240 rocprofv3 --pmc $CNT --output-format csv -d $OUT/pmc -o pmc -- python3 bench.py --cpu-steps 0 --steps 4 --warmup 2 --roofline-steps 0 --streams 1 --no-extras > /dev/null 2> $OUT/prof_pmc.err
 echo "pmc done"
 python3 - <<PY
 import csv, glob, collections

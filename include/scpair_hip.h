@@ -159,7 +159,7 @@ int scp_ln_act_bwd(const float* dOut, long ldo, const float* xhat, long ldx, con
  *           xhat2 [B][H2], rstd2 [B] are written for the backward (all null: inference).
  *      bwd: dOut [B][N3 or H2] -> the gradient of the first-layer product as fp32 dY1 [B][ldy] and / or as the
  *           transposed bf16 dYT [H1][ldt] scp_spmm_dw_*bf16 takes (ldt >= B rounded up to 64; either may be null), and
- *           the gradients of every tensor of the tail (each nullable); ws: scp_enc_tail_ws_floats(B, H1, H2, N3) floats. ---- */
+ *           the gradients of every tensor of the tail (each nullable); ws: scp_enc_tail_ws_floats(B, H1, H2, N3, C) floats. ---- */
 #define SCP_ENC_TAIL_MAX_BRANCHES 4
 typedef struct {
   int B, H1, H2, N3;
@@ -179,9 +179,20 @@ typedef struct {
   void* dYT; long ldt;
   float* ws;
   float *dg1, *dbe1, *db1, *dW2, *dg2, *dbe2, *db2, *dW3, *db3;
+  /* covariate block appended to the encoder input (model.py:128: torch.cat([input, input_batch])): cov [B][ldcov], C <= 64
+   * columns (0: none); W1c = the first-layer weight's columns F .. F+C-1 (pointer W1 + F, row stride ldw1c = F + C).
+   * backward: the gradient of those columns goes to dW1c [H1][lddw1c] (the same columns of the layer's gradient;
+   * nullable), or -- adam != 0, single-process training with the first layer's AdamW step fused into its weight-gradient
+   * kernel -- is consumed by the AdamW step of W1c in place (adam_m / adam_v / adam_sh point at the same columns of the
+   * moments and of the bf16 shadow; hyper-parameters as in scp_spmm_dw_adamw_bf16) */
+  const float* cov; long ldcov; int C;
+  const float* W1c; long ldw1c;
+  float* dW1c; long lddw1c;
+  int adam; float *adam_m, *adam_v; void* adam_sh; long adam_ldsh;
+  float lr, wd, beta1, beta2, adam_eps, bc1, bc2, gscale; const float* bc_dev;
 } ScpEncTail;
 int scp_enc_tail_fwd(const ScpEncTail* branches, int nbranch, void* stream);
-long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3);
+long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3, int C);
 int scp_enc_tail_bwd(const ScpEncTail* branches, int nbranch, void* stream);
 
 /* ---- Bernoulli decoder + BCE, fused forward(+backward): Output_Module_Ber.forward (model.py:164-190)

@@ -38,7 +38,11 @@ class EncTail(C.Structure):
                 ("slabs", P), ("slab_stride", L), ("ld_slab", L), ("nslab", I), ("out", P), ("ldo", L),
                 ("dOut", P), ("lddo", L), ("dY1", P), ("ldy", L), ("dYT", P), ("ldt", L), ("ws", P),
                 ("dg1", P), ("dbe1", P), ("db1", P), ("dW2", P), ("dg2", P), ("dbe2", P), ("db2", P), ("dW3", P),
-                ("db3", P)]
+                ("db3", P),
+                ("cov", P), ("ldcov", L), ("C", I), ("W1c", P), ("ldw1c", L), ("dW1c", P), ("lddw1c", L),
+                ("adam", I), ("adam_m", P), ("adam_v", P), ("adam_sh", P), ("adam_ldsh", L),
+                ("lr", F), ("wd", F), ("beta1", F), ("beta2", F), ("adam_eps", F), ("bc1", F), ("bc2", F), ("gscale", F),
+                ("bc_dev", P)]
 
 
 _SIGS = {
@@ -75,7 +79,7 @@ _SIGS = {
     "scp_ln_act_bwd_grid": (I, [I]),
     "scp_ln_act_bwd": (I, [P, L, P, L, P, P, P, I, I, F, F, U64, P, P, L, P, P, P, P, P]),
     "scp_enc_tail_fwd": (I, [C.POINTER(EncTail), I, P]),
-    "scp_enc_tail_ws_floats": (L, [I, I, I, I]),
+    "scp_enc_tail_ws_floats": (L, [I, I, I, I, I]),
     "scp_enc_tail_bwd": (I, [C.POINTER(EncTail), I, P]),
     "scp_dec_chunks": (I, [I]),
     "scp_dec_kp": (I, [I]),

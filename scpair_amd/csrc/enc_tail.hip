@@ -6,6 +6,9 @@
 //                                       -> Linear(H1, H2) -> LayerNorm -> LeakyReLU -> Dropout         (second FCNN layer)
 //                                       -> Linear(H2, N3)   (extra_linear_rep, model.py:83-84; the library head
 //                                                            Linear(H2, 1), model.py:92; N3 = 0: none)
+// An optional covariate block (model.py:128: torch.cat([x, cov]) in front of the first layer) enters after the slab sum
+// as cov W1[:, F:]^T; the gradient of those weight columns comes out of the backward's records, either as a strided
+// block of the layer's gradient or consumed by the AdamW step of those columns in the reduction kernel.
 //
 // The work is row-local and tiny (2 B H1 H2 flop), so it runs in exact fp32 on the vector units.  A wave owns FOUR
 // cells: every row of W2 it loads from L2 is used four times, and the four dot products of a W2 row are reduced
@@ -92,15 +95,17 @@ template <int RW> __device__ __forceinline__ float reduce_rw(const float (&v)[RW
 // block are waited for at its end): the chunk count is a template parameter, lanes past H1 read a clamped address and
 // mask the value, and the H2 loop is a runtime loop inside at most RW blocks of QN columns.
 struct TailOff {
-  int g1, be1, b1, g2, be2, b2, w3, b3, pv;
+  int g1, be1, b1, g2, be2, b2, w3, b3, wc, pv;
 };
 // Layout of one wave's partial-gradient record (PV floats, PV % 4 == 0):
-//   dgamma1[H1] dbeta1[H1] dbias1[H1] dgamma2[H2] dbeta2[H2] dbias2[H2] dW3[N3*H2] db3[N3]
-static __host__ __device__ inline TailOff tail_off(int H1, int H2, int N3) {
+//   dgamma1[H1] dbeta1[H1] dbias1[H1] dgamma2[H2] dbeta2[H2] dbias2[H2] dW3[N3*H2] db3[N3] (pad to 4) dW1c[C][H1]
+// (dW1c: gradient of the first-layer weight columns that multiply the covariate block, C = 0: none)
+static __host__ __device__ inline TailOff tail_off(int H1, int H2, int N3, int C) {
   TailOff o;
   o.g1 = 0; o.be1 = H1; o.b1 = 2 * H1; o.g2 = 3 * H1; o.be2 = o.g2 + H2; o.b2 = o.be2 + H2; o.w3 = o.b2 + H2;
   o.b3 = o.w3 + N3 * H2;
-  o.pv = (o.b3 + N3 + 3) / 4 * 4;
+  o.wc = (o.b3 + N3 + 3) / 4 * 4;
+  o.pv = o.wc + C * H1;                             // H1 % 4 == 0
   return o;
 }
 #define ETW_ROWS 64
@@ -109,12 +114,12 @@ struct TailWs {
   int nrec, nchunk;
   long wn, o_slab, o_dz2, total;
 };
-static __host__ __device__ inline TailWs tail_ws(int B, int H1, int H2, int N3) {
+static __host__ __device__ inline TailWs tail_ws(int B, int H1, int H2, int N3, int C) {
   TailWs w;
   w.nrec = (B + ET_RW - 1) / ET_RW;
   w.nchunk = (B + ETW_ROWS - 1) / ETW_ROWS;
   w.wn = (long)H2 * H1;
-  w.o_slab = (long)w.nrec * tail_off(H1, H2, N3).pv;
+  w.o_slab = (long)w.nrec * tail_off(H1, H2, N3, C).pv;
   w.o_dz2 = w.o_slab + w.nchunk * w.wn;
   w.total = w.o_dz2 + (long)B * H2 + 8;
   return w;
@@ -199,6 +204,21 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
       for (int r = 0; r < ET_RW; r++)
 #pragma unroll
         for (int c = 0; c < NCH; c++) v[r][c] += t[r][c];
+    }
+  }
+  // covariate block of the input (model.py:128 concatenates it to x): + cov[cell][j] * W1[k][F + j], exact fp32
+  for (int j = 0; j < m.C; j++) {
+    f4 wj[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const float* w = m.W1c + (long)ko[c] * m.ldw1c + j;
+      wj[c] = f4{w[0], w[m.ldw1c], w[2 * m.ldw1c], w[3 * m.ldw1c]};
+    }
+#pragma unroll
+    for (int r = 0; r < ET_RW; r++) {
+      const float cv = m.cov[(long)rowc[r] * m.ldcov + j];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) v[r][c] += cv * wj[c];
     }
   }
   // LayerNorm 1 (two-pass statistics, biased variance: nn.LayerNorm), activation, dropout
@@ -379,8 +399,8 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
   const int row0 = rec_i * ET_RW;
   if (row0 >= B) return;                          // no barrier below
   const int NO = N3 > 0 ? N3 : H2;                 // width of dOut
-  const TailOff off = tail_off(H1, H2, N3);
-  const TailWs wsl = tail_ws(B, H1, H2, N3);
+  const TailOff off = tail_off(H1, H2, N3, m.C);
+  const TailWs wsl = tail_ws(B, H1, H2, N3, m.C);
   float* rec = m.ws + (long)rec_i * off.pv;
   float* dz2g = m.ws + wsl.o_dz2;
   const uint64_t sd1 = m.seed1 + (m.seed_dev ? m.seed_dev[0] : 0), sd2 = m.seed2 + (m.seed_dev ? m.seed_dev[0] : 0);
@@ -569,6 +589,20 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
       if (m.dY1 && ok[c] && live) *(f4*)(m.dY1 + (long)row * m.ldy + ko[c]) = cd;
     }
   }
+  // gradient of the covariate columns of W1: dW1c[k][j] = sum over cells of dY1[cell][k] cov[cell][j]; the wave's share
+  // goes into its record as [j][k] (dead cells carry dY1 = 0)
+  for (int j = 0; j < m.C; j++) {
+    float cv[ET_RW];
+#pragma unroll
+    for (int r = 0; r < ET_RW; r++) cv[r] = m.cov[(long)min(row0 + r, B - 1) * m.ldcov + j];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      f4 t = cv[0] * da[0][c];
+#pragma unroll
+      for (int r = 1; r < ET_RW; r++) t += cv[r] * da[r][c];
+      if (ok[c]) *(f4*)(rec + off.wc + (long)j * H1 + ko[c]) = t;
+    }
+  }
   if (m.dYT) {
     // transposed bf16 copy [H1][ldt]: the wave's cells are consecutive columns -> one store per row
     // of dY^T (cells past the batch end hold 0; ldt covers the batch rounded up to 64)
@@ -609,7 +643,7 @@ __global__ __launch_bounds__(256) void enc_tail_w2_kernel(TailSet S) {
   const int tid = threadIdx.x, kq = tid & 31, slot = tid >> 5;
   const int H1 = m.H1, H2 = m.H2;
   if (blockIdx.x * 128 >= H1 || !m.dW2) return;    // uniform: a narrower branch of the same launch
-  const TailWs wsl = tail_ws(m.B, H1, H2, m.N3);
+  const TailWs wsl = tail_ws(m.B, H1, H2, m.N3, m.C);
   const float* dz2g = m.ws + wsl.o_dz2;
   float* slab = m.ws + wsl.o_slab;
   const int k = blockIdx.x * 128 + kq * 4;
@@ -664,6 +698,12 @@ struct TailRed {
   const float* slab; int nchunk; long wn;
   int seg_beg[8]; int seg_end[8]; float* seg_dst[8];
   float* dW2;
+  // covariate-weight segment [wc_beg, wc_beg + C * H1), element (j, k) -> column j of row k of the first-layer weight:
+  // written as a gradient (dW1c [H1][lddw1c]) or, adam != 0, consumed by the AdamW step of those weights in place
+  int wc_beg, wc_end, H1, adam;
+  float* dW1c; long lddw1c;
+  float* W1c; long ldw1c; float* adam_m; float* adam_v; __bf16* adam_sh; long adam_ldsh;
+  float lr, wd, b1, b2, eps, bc1, bc2, gscale; const float* bc_dev;
 };
 struct TailRedSet {
   TailRed b[SCP_ENC_TAIL_MAX_BRANCHES];
@@ -696,6 +736,23 @@ __global__ __launch_bounds__(256) void enc_tail_reduce_kernel(TailRedSet R) {
   if (q != 0 || n == 0) return;
   s = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
   if (in_part) {
+    if (i >= r.wc_beg && i < r.wc_end) {
+      const int idx = (int)(i - r.wc_beg), j = idx / r.H1, k = idx - j * r.H1;
+      if (r.adam) {
+        const float bc1 = r.bc_dev ? r.bc_dev[0] : r.bc1, bc2 = r.bc_dev ? r.bc_dev[1] : r.bc2;
+        const AdamHyper hy = adam_hyper(r.lr, r.wd, r.b1, r.b2, r.eps, bc1, bc2, r.gscale);
+        const long o = (long)k * r.ldw1c + j;
+        float p_ = r.W1c[o], m_ = r.adam_m[o], v_ = r.adam_v[o];
+        adamw_update_fast(hy, p_, s, m_, v_);      // same arithmetic as the epilogue that updates the other columns
+        r.W1c[o] = p_;
+        r.adam_m[o] = m_;
+        r.adam_v[o] = v_;
+        if (r.adam_sh) r.adam_sh[(long)k * r.adam_ldsh + j] = (__bf16)p_;
+      } else if (r.dW1c) {
+        r.dW1c[(long)k * r.lddw1c + j] = s;
+      }
+      return;
+    }
     for (int g_ = 0; g_ < 8; g_++)
       if (i >= r.seg_beg[g_] && i < r.seg_end[g_] && r.seg_dst[g_]) r.seg_dst[g_][i - r.seg_beg[g_]] = s;
   } else {
@@ -718,6 +775,8 @@ static int tail_check(const ScpEncTail* ms, int nb, const char* who) {
     SCP_CHECK((((uintptr_t)m->b1 | (uintptr_t)m->g1 | (uintptr_t)m->be1 | (uintptr_t)m->W2 | (uintptr_t)m->xhat1) & 15) == 0,
               SCP_ERR_SHAPE, "%s: H1-wide tensors must be 16-byte aligned", who);
     SCP_CHECK(m->p1 >= 0.f && m->p1 < 1.f && m->p2 >= 0.f && m->p2 < 1.f, SCP_ERR_ARG, "%s: dropout p must be in [0,1)", who);
+    SCP_CHECK(m->C >= 0 && m->C <= 64 && (m->C == 0 || (m->cov && m->W1c && m->ldcov >= m->C && m->ldw1c >= m->C)), SCP_ERR_ARG,
+              "%s: covariate block needs cov [B][ldcov >= C], W1c with row stride >= C, C <= 64 (got C = %d)", who, m->C);
   }
   return SCP_OK;
 }
@@ -755,7 +814,7 @@ extern "C" int scp_enc_tail_fwd(const ScpEncTail* ms, int nbranch, void* stream_
   return SCP_OK;
 }
 
-extern "C" long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3) { return tail_ws(B, H1, H2, N3).total; }
+extern "C" long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3, int C) { return tail_ws(B, H1, H2, N3, C).total; }
 
 extern "C" int scp_enc_tail_bwd(const ScpEncTail* ms, int nbranch, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -777,8 +836,8 @@ extern "C" int scp_enc_tail_bwd(const ScpEncTail* ms, int nbranch, void* stream_
     SCP_CHECK(((uintptr_t)m->ws & 15) == 0, SCP_ERR_SHAPE, "scp_enc_tail_bwd: ws must be 16-byte aligned");
     SCP_CHECK(m->lddo >= (m->N3 > 0 ? m->N3 : m->H2), SCP_ERR_ARG, "scp_enc_tail_bwd: dOut leading dimension too small");
     S.b[b] = *m;
-    const TailOff off = tail_off(m->H1, m->H2, m->N3);
-    const TailWs w = tail_ws(B, m->H1, m->H2, m->N3);
+    const TailOff off = tail_off(m->H1, m->H2, m->N3, m->C);
+    const TailWs w = tail_ws(B, m->H1, m->H2, m->N3, m->C);
     TailRed& r = R.b[b];
     r.part = m->ws; r.nblk = w.nrec; r.pv = off.pv; r.slab = m->ws + w.o_slab; r.nchunk = w.nchunk; r.wn = w.wn;
     r.dW2 = m->dW2;
@@ -786,6 +845,18 @@ extern "C" int scp_enc_tail_bwd(const ScpEncTail* ms, int nbranch, void* stream_
     const int ends[8] = {off.be1, off.b1, off.g2, off.be2, off.b2, off.w3, off.b3, off.b3 + m->N3};
     float* dsts[8] = {m->dg1, m->dbe1, m->db1, m->dg2, m->dbe2, m->db2, m->dW3, m->db3};
     for (int q = 0; q < 8; q++) { r.seg_beg[q] = begs[q]; r.seg_end[q] = ends[q]; r.seg_dst[q] = dsts[q]; }
+    r.wc_beg = off.wc; r.wc_end = off.wc + m->C * m->H1; r.H1 = m->H1; r.adam = m->C > 0 ? m->adam : 0;
+    r.dW1c = m->dW1c; r.lddw1c = m->lddw1c;
+    if (r.adam) {
+      SCP_CHECK(m->adam_m && m->adam_v && (m->bc_dev || (m->bc1 > 0.f && m->bc2 > 0.f)), SCP_ERR_ARG,
+                "scp_enc_tail_bwd: the AdamW step of the covariate weights needs moments and bias corrections > 0");
+      r.W1c = const_cast<float*>(m->W1c); r.ldw1c = m->ldw1c; r.adam_m = m->adam_m; r.adam_v = m->adam_v;
+      r.adam_sh = (__bf16*)m->adam_sh; r.adam_ldsh = m->adam_ldsh;
+      r.lr = m->lr; r.wd = m->wd; r.b1 = m->beta1; r.b2 = m->beta2; r.eps = m->adam_eps; r.bc1 = m->bc1; r.bc2 = m->bc2;
+      r.gscale = m->gscale; r.bc_dev = m->bc_dev;
+    } else {
+      SCP_CHECK(m->C == 0 || !m->dW1c || m->lddw1c >= m->C, SCP_ERR_ARG, "scp_enc_tail_bwd: dW1c leading dimension too small");
+    }
     max_h1 = m->H1 > max_h1 ? m->H1 : max_h1;
     any_w2 |= m->dW2 != nullptr;
     const long total = off.pv + w.wn;

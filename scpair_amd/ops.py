@@ -531,9 +531,15 @@ ENC_MAX_BRANCHES = 4
 
 
 def enc_branch_supported(x, cov, W1, W2, W3, ln1, ln2):
-    """The fused path covers the reference's default encoder shape: sparse minibatch, no covariate block, two FCNN
-    layers with LayerNorm, hidden widths H1 % 4 == 0, H1 <= 1024, H2 <= 64, final Linear with N3 <= 64 outputs."""
-    if not isinstance(x, BatchTiles) or cov is not None or not ln1 or not ln2:
+    """The fused path covers the reference's default encoder shape: sparse minibatch, optionally a covariate block of
+    up to 64 columns (cov=['labels'] is the reference constructor's default), two FCNN layers with LayerNorm, hidden widths
+    H1 % 4 == 0, H1 <= 1024, H2 <= 64, final Linear with N3 <= 64 outputs."""
+    if not isinstance(x, BatchTiles) or not ln1 or not ln2:
+        return False
+    if cov is not None and not (torch.is_tensor(cov) and cov.is_cuda and cov.ndim == 2 and 0 < cov.shape[1] <= 64
+                                and cov.shape[0] == x.shape[0]):
+        return False
+    if W1.shape[1] != x.shape[1] + (0 if cov is None else cov.shape[1]):
         return False
     H1, H2 = W1.shape[0], W2.shape[0]
     if H1 % 4 or H1 > 1024 or H2 > 64 or W2.shape[1] != H1 or (W3 is not None and (W3.shape[0] > 64 or W3.shape[1] != H2)):
@@ -567,13 +573,18 @@ class EncBranchesFn(torch.autograd.Function):
         H1s = [p_[0].shape[0] for p_ in P]
         H2s = [p_[4].shape[0] for p_ in P]
         N3s = [0 if p_[8] is None else p_[8].shape[0] for p_ in P]
+        cov = cfg.get("cov")                        # [B, C] covariate block concatenated to the input (model.py:128), or None
+        cov = None if cov is None else _f32c(cov)
+        Cn = 0 if cov is None else cov.shape[1]
+        Ft = F + Cn                                 # columns of the first-layer weights
         for p_ in P:
-            if p_[0].shape[1] != F:
-                raise ValueError(f"encoder: first layer expects {p_[0].shape[1]} inputs, the minibatch has {F} features")
+            if p_[0].shape[1] != Ft:
+                raise ValueError(f"encoder: first layer expects {p_[0].shape[1]} inputs, the minibatch has {F} features"
+                                 f" (+{Cn} covariates)")
         shadows = [b_["shadow"] for b_ in cfg["br"]]
         use_bf = ns == 1 and all(sh is not None for sh in shadows)
         # one first-layer launch for both branches when their weights (and bf16 shadows) are adjacent row blocks
-        merged = (nb == 2 and use_bf and _rows_adjacent(P[0][0], P[1][0], 4 * F)
+        merged = (nb == 2 and use_bf and _rows_adjacent(P[0][0], P[1][0], 4 * Ft)
                   and shadows[0].shape[1] == shadows[1].shape[1]
                   and _rows_adjacent(shadows[0], shadows[1], 2 * shadows[0].shape[1]))
         groups = [list(range(nb))] if merged else [[i] for i in range(nb)]
@@ -611,7 +622,7 @@ class EncBranchesFn(torch.autograd.Function):
                                                sh.shape[1], slabs[gi].data_ptr(), Hg, nsplits[gi], stream),
                            "scp_spmm_fwd_bf16")
             else:
-                _lib.check(L.scp_spmm_fwd(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(), F,
+                _lib.check(L.scp_spmm_fwd(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(), Ft,
                                           slabs[gi].data_ptr(), Hg, None, nsplits[gi], ns, stream), "scp_spmm_fwd")
             col = 0
             for i in g:
@@ -634,12 +645,16 @@ class EncBranchesFn(torch.autograd.Function):
             m.xhat1, m.rstd1, m.xhat2, m.rstd2 = _lib.ptr(xh1), _lib.ptr(r1), _lib.ptr(xh2), _lib.ptr(r2)
             m.slabs, m.slab_stride, m.ld_slab, m.nslab = slab_of[i]
             m.out, m.ldo = outs[i].data_ptr(), nouts[i]
+            if Cn:
+                m.cov, m.ldcov, m.C = cov.data_ptr(), Cn, Cn
+                m.W1c, m.ldw1c = W1.data_ptr() + 4 * F, Ft
         _lib.check(L.scp_enc_tail_fwd(arr, nb, stream), "scp_enc_tail_fwd")
         if train:
             ctx.arr, ctx.tiles, ctx.buf, ctx.cfg = arr, x, buf, cfg
+            ctx.cov = cov
             ctx.save_for_backward(*[t for t in tensors if t is not None])
             ctx.present = [t is not None for t in tensors]
-            ctx.dims = (Bn, F, H1s, H2s, N3s, ns, use_bf, groups)
+            ctx.dims = (Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn)
         return tuple(outs)
 
     @staticmethod
@@ -647,7 +662,8 @@ class EncBranchesFn(torch.autograd.Function):
         L = _lib.lib()
         it = iter(ctx.saved_tensors)
         tensors = [next(it) if pr else None for pr in ctx.present]
-        Bn, F, H1s, H2s, N3s, ns, use_bf, groups = ctx.dims
+        Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn = ctx.dims
+        Ft = F + Cn
         nb = len(H1s)
         P = [tensors[10 * i:10 * i + 10] for i in range(nb)]
         cfg, arr, t = ctx.cfg, ctx.arr, ctx.tiles
@@ -657,7 +673,7 @@ class EncBranchesFn(torch.autograd.Function):
         # one allocation for every small gradient and the workspaces; the first-layer gradient operand separately
         sizes = []
         for i in range(nb):
-            nws = L.scp_enc_tail_ws_floats(Bn, H1s[i], H2s[i], N3s[i])
+            nws = L.scp_enc_tail_ws_floats(Bn, H1s[i], H2s[i], N3s[i], Cn)
             sizes += [H1s[i], H1s[i], H1s[i], H2s[i], H2s[i], H2s[i], N3s[i] * H2s[i], N3s[i], H2s[i] * H1s[i], nws,
                       0 if use_bf else Bn * H1s[i]]
         gb, pieces = _carve(sizes, dev)
@@ -671,6 +687,46 @@ class EncBranchesFn(torch.autograd.Function):
                 for i in g:
                     dYT[i] = (tbuf, row)
                     row += H1s[i]
+        # ---- how the first-layer weight gradient of every branch is produced: decided before the tail's backward runs,
+        # because with a covariate block that kernel's reduction writes (or consumes) the gradient of the weight columns
+        # F .. F+C-1.  A unit = the branches one weight-gradient launch covers; mode 'fused': AdamW step in the kernel's
+        # epilogue, 'sink': bf16 into the exchange buffer, 'plain': fp32 gradient for autograd ----
+        plan = []               # (branches, mode, payload)
+        if not use_bf:
+            for i in range(nb):
+                if need_w1[i]:
+                    plan.append(([i], "plain32", torch.empty((H1s[i], Ft), dtype=torch.float32, device=dev)))
+        else:
+            fuse_ok = F % 4 == 0 and Ft % 4 == 0
+            for g in groups:
+                if not any(need_w1[i] for i in g):
+                    continue
+                units = [g]
+                if len(g) == 2:
+                    fz = [cfg["br"][i]["fused"] if fuse_ok else None for i in g]
+                    sk = [cfg["br"][i]["sink"] for i in g]
+                    if fz[0] is not None and fz[1] is not None:
+                        if not _fused_pair_ok(fz[0], fz[1], P[g[0]][0], P[g[1]][0]):
+                            units = [[g[0]], [g[1]]]
+                    elif fz[0] is not None or fz[1] is not None or (sk[0] is None) != (sk[1] is None) \
+                            or (sk[0] is not None and not _rows_adjacent(sk[0].view, sk[1].view, 2 * F)) \
+                            or not all(need_w1[i] for i in g):
+                        units = [[g[0]], [g[1]]]
+                for u in units:
+                    if not need_w1[u[0]]:
+                        continue
+                    fz = cfg["br"][u[0]]["fused"] if fuse_ok else None
+                    sk = cfg["br"][u[0]]["sink"] if fz is None else None
+                    if fz is not None:
+                        st = fz.begin_step(P[u[0]][0])
+                        for i in u[1:]:
+                            cfg["br"][i]["fused"].begin_step(P[i][0])
+                        plan.append((u, "fused", st))
+                    elif sk is not None:
+                        plan.append((u, "sink", sk))
+                    else:
+                        Hu = sum(H1s[i] for i in u)
+                        plan.append((u, "plain", torch.empty((Hu, Ft), dtype=torch.float32, device=dev)))
         keep = []
         grads = []
         for i in range(nb):
@@ -692,70 +748,70 @@ class EncBranchesFn(torch.autograd.Function):
             m.dg1, m.dbe1, m.db1 = dg1.data_ptr(), dbe1.data_ptr(), _lib.ptr(db1 if b1 is not None else None)
             m.dW2, m.dg2, m.dbe2, m.db2 = dW2.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr()
             m.dW3, m.db3 = _lib.ptr(dW3 if N3s[i] else None), _lib.ptr(db3 if N3s[i] else None)
+            m.dW1c, m.lddw1c, m.adam = None, 0, 0
             grads.append([None, db1 if b1 is not None else None, dg1, dbe1, dW2.view(H2s[i], H1s[i]), db2, dg2, dbe2,
                           dW3.view(N3s[i], H2s[i]) if N3s[i] else None, db3 if N3s[i] else None])
+        if Cn:
+            # the covariate columns of each branch's first-layer gradient (or their AdamW step) come out of the tail
+            for u, mode, payload in plan:
+                row_ = 0
+                for i in u:
+                    m = arr[i]
+                    if mode in ("plain", "plain32"):
+                        m.dW1c, m.lddw1c = payload.data_ptr() + 4 * (row_ * Ft + F), Ft
+                    elif mode == "fused":
+                        fz_i = cfg["br"][i]["fused"]
+                        p_i = fz_i.param
+                        st_i = fz_i.opt.state[p_i]
+                        sh_i = shadow_of(p_i)
+                        lr, wd, b1_, b2_, eps_, bc1, bc2, gs, bc_dev = payload[3]
+                        m.adam = 1
+                        m.adam_m, m.adam_v = st_i["exp_avg"].data_ptr() + 4 * F, st_i["exp_avg_sq"].data_ptr() + 4 * F
+                        m.adam_sh, m.adam_ldsh = sh_i.data_ptr() + 2 * F, sh_i.shape[1]
+                        m.lr, m.wd, m.beta1, m.beta2, m.adam_eps = lr, wd, b1_, b2_, eps_
+                        m.bc1, m.bc2, m.gscale, m.bc_dev = bc1, bc2, gs, bc_dev
+                    else:
+                        raise RuntimeError("encoder with a covariate block: the bf16 gradient sink is not supported")
+                    row_ += H1s[i]
         _lib.check(L.scp_enc_tail_bwd(arr, nb, stream), "scp_enc_tail_bwd")
         # ---- first-layer weight gradient (and, where registered, the AdamW step in its epilogue) -------------------
         tp, tk, tv, tpk = _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), _lib.ptr(t.pk)
-        if not use_bf:
-            for i in range(nb):
-                if need_w1[i]:
-                    dW1 = torch.empty((H1s[i], F), dtype=torch.float32, device=dev)
-                    _lib.check(L.scp_spmm_dw(Bn, H1s[i], F, tp, tk, tv, arr[i].dY1, H1s[i], dW1.data_ptr(), F, ns, stream),
-                               "scp_spmm_dw")
-                    grads[i][0] = dW1
-        else:
-            for g in groups:
-                if not any(need_w1[i] for i in g):
-                    continue
-                units = [g]
-                if len(g) == 2:
-                    fz = [cfg["br"][i]["fused"] if F % 4 == 0 else None for i in g]
-                    sk = [cfg["br"][i]["sink"] for i in g]
-                    if fz[0] is not None and fz[1] is not None:
-                        if not _fused_pair_ok(fz[0], fz[1], P[g[0]][0], P[g[1]][0]):
-                            units = [[g[0]], [g[1]]]
-                    elif fz[0] is not None or fz[1] is not None or (sk[0] is None) != (sk[1] is None) \
-                            or (sk[0] is not None and not _rows_adjacent(sk[0].view, sk[1].view, 2 * F)) \
-                            or not all(need_w1[i] for i in g):
-                        units = [[g[0]], [g[1]]]
-                for u in units:
-                    if not need_w1[u[0]]:
-                        continue
-                    Hu = sum(H1s[i] for i in u)
-                    tbuf, row = dYT[u[0]]
-                    dyt_ptr = tbuf.data_ptr() + 2 * row * ldt
-                    W1 = P[u[0]][0]
-                    fz = cfg["br"][u[0]]["fused"] if F % 4 == 0 else None
-                    sk = cfg["br"][u[0]]["sink"] if fz is None else None
-                    if fz is not None:
-                        m_, v_, sh_, hp = fz.begin_step(W1)
-                        for i in u[1:]:
-                            cfg["br"][i]["fused"].begin_step(P[i][0])
-                        tm = _cfg["fused_timer"]
-                        if tm is not None:
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                        _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, W1.data_ptr(), F,
-                                                            m_.data_ptr(), v_.data_ptr(), sh_.data_ptr(), sh_.shape[1],
-                                                            *hp, stream), "scp_spmm_dw_adamw_bf16")
-                        if tm is not None:
-                            e1.record()
-                            tm.append((e0, e1, Hu * F, int(t.nnz) * (8 if t.val is not None else 4) + 2 * Hu * ldt, "spmm_dw_adamw"))
-                    elif sk is not None:
-                        _lib.check(L.scp_spmm_dw_bf16_g16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, sk.view.data_ptr(), F, stream),
-                                   "scp_spmm_dw_bf16_g16")
-                        for i in u:
-                            cfg["br"][i]["sink"].written = True
-                    else:
-                        dW = torch.empty((Hu, F), dtype=torch.float32, device=dev)
-                        _lib.check(L.scp_spmm_dw_bf16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, dW.data_ptr(), F, stream),
-                                   "scp_spmm_dw_bf16")
-                        row_ = 0
-                        for i in u:
-                            grads[i][0] = dW[row_:row_ + H1s[i]]
-                            row_ += H1s[i]
-        ctx.buf = ctx.tiles = ctx.arr = None
+        for u, mode, payload in plan:
+            Hu = sum(H1s[i] for i in u)
+            W1 = P[u[0]][0]
+            if mode == "plain32":
+                i = u[0]
+                _lib.check(L.scp_spmm_dw(Bn, H1s[i], F, tp, tk, tv, arr[i].dY1, H1s[i], payload.data_ptr(), Ft, ns, stream),
+                           "scp_spmm_dw")
+                grads[i][0] = payload
+                continue
+            tbuf, row = dYT[u[0]]
+            dyt_ptr = tbuf.data_ptr() + 2 * row * ldt
+            if mode == "fused":
+                m_, v_, sh_, hp = payload
+                tm = _cfg["fused_timer"]
+                if tm is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, W1.data_ptr(), Ft,
+                                                    m_.data_ptr(), v_.data_ptr(), sh_.data_ptr(), sh_.shape[1],
+                                                    *hp, stream), "scp_spmm_dw_adamw_bf16")
+                if tm is not None:
+                    e1.record()
+                    tm.append((e0, e1, Hu * F, int(t.nnz) * (8 if t.val is not None else 4) + 2 * Hu * ldt, "spmm_dw_adamw"))
+            elif mode == "sink":
+                _lib.check(L.scp_spmm_dw_bf16_g16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, payload.view.data_ptr(), F, stream),
+                           "scp_spmm_dw_bf16_g16")
+                for i in u:
+                    cfg["br"][i]["sink"].written = True
+            else:
+                _lib.check(L.scp_spmm_dw_bf16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, payload.data_ptr(), Ft, stream),
+                           "scp_spmm_dw_bf16")
+                row_ = 0
+                for i in u:
+                    grads[i][0] = payload[row_:row_ + H1s[i]]
+                    row_ += H1s[i]
+        ctx.buf = ctx.tiles = ctx.arr = ctx.cov = None
         flat = [None, None]
         for i in range(nb):
             flat += grads[i]
@@ -779,13 +835,14 @@ def _fused_pair_ok(fa, fb, Wa, Wb):
             and sha.shape[1] == shb.shape[1] and _rows_adjacent(sha, shb, 2 * sha.shape[1]))
 
 
-def enc_branches(x, branches, slope, seeds=None):
+def enc_branches(x, branches, slope, seeds=None, cov=None):
     """branches: list of dicts with W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 (W3 / b3 / b1 may be None) and optional
     p1, p2, eps1, eps2.  seeds: optional list of (seed1, seed2) per branch (tests); drawn from next_seed() otherwise.
+    cov: optional [B, C] covariate block the reference concatenates to the input (model.py:128); W1 is then [H1, F + C].
     Returns the list of branch outputs."""
     if not 1 <= len(branches) <= ENC_MAX_BRANCHES:
         raise ValueError("enc_branches: 1..%d branches" % ENC_MAX_BRANCHES)
-    cfg = {"slope": float(slope), "br": []}
+    cfg = {"slope": float(slope), "br": [], "cov": cov}
     tensors = []
     grad_on = torch.is_grad_enabled()
     for i, b in enumerate(branches):
@@ -796,7 +853,7 @@ def enc_branches(x, branches, slope, seeds=None):
             shadow = shadow_of(W1)
             if grad_on and W1.requires_grad:
                 fused = fused_handle(W1)
-                sink = grad_sink_of(W1) if fused is None else None
+                sink = grad_sink_of(W1) if (fused is None and cov is None) else None
         if seeds is not None:
             s1, s2 = seeds[i]
         else:

@@ -80,8 +80,8 @@ class HipFCNN(nn.Sequential):
 
 def _branch_spec(fcnn, final, x, cov):
     """The tensors of an encoder branch the fused path (ops.enc_branches) takes, or None when the branch has another
-    shape than the reference's default (sparse minibatch, no covariate block, two FCNN layers with LayerNorm and no
-    BatchNorm, a Linear with bias behind them or none)."""
+    shape than the reference's default (sparse minibatch, optionally a covariate block, two FCNN layers with LayerNorm
+    and no BatchNorm, a Linear with bias behind them or none)."""
     groups = fcnn._groups() if isinstance(fcnn, HipFCNN) else None
     if groups is None or len(groups) != 2:
         return None
@@ -117,7 +117,7 @@ def encoder_branches(branches, x, cov=None):
         idx = idx[:ops.ENC_MAX_BRANCHES]
         if len(idx) == 2 and ops.get_precision() == "bf16":
             ops.pack_first_layers(specs[idx[0]]["W1"], specs[idx[1]]["W1"])
-        res = ops.enc_branches(x, [specs[i] for i in idx], slope)
+        res = ops.enc_branches(x, [specs[i] for i in idx], slope, cov=cov)
         for i, r in zip(idx, res):
             outs[i] = r
     for i, (f, fin) in enumerate(branches):

@@ -31,14 +31,18 @@ def _params(g, F, H1, H2, N3):
     return P
 
 
-def _ref(P, x, rnd, keep1=None, keep2=None):
-    """fp64 forward; `rnd` rounds the first-layer operands the way the precision mode does; keep1 / keep2: dropout
+def _ref(P, x, rnd, keep1=None, keep2=None, cov=None):
+    """fp64 forward (cov: covariate block the reference concatenates to the input, model.py:128; its weight columns
+    stay exact fp32 in both precision modes); `rnd` rounds the first-layer operands the way the precision mode does; keep1 / keep2: dropout
     factors (0 or 1/(1-p)) of the two layers.  Also returns the smallest |pre-activation|: an element closer to the
     LeakyReLU kink than the fp32 / fp64 difference can sit on the other side of it in the kernel, which changes its
     gradient by a factor 100 -- the tests draw their parameters so that no element is that close."""
     q = {k: v.double().requires_grad_(True) for k, v in P.items()}
-    W1 = q["W1"] + (rnd(P["W1"]) - P["W1"].double()).detach()
+    F = x.shape[1]
+    W1 = q["W1"][:, :F] + (rnd(P["W1"][:, :F]) - P["W1"][:, :F].double()).detach()
     y = rnd(x) @ W1.t() + q["b1"]
+    if cov is not None:
+        y = y + cov.double() @ q["W1"][:, F:].t()
     z1 = Fn.layer_norm(y, (y.shape[1],), q["g1"], q["be1"])
     a1 = Fn.leaky_relu(z1, 0.01)
     if keep1 is not None:
@@ -51,10 +55,10 @@ def _ref(P, x, rnd, keep1=None, keep2=None):
     return q, out, min(float(z1.detach().abs().min()), float(z2.detach().abs().min()))
 
 
-def _draw(F, H1, H2, N3, x, rnd, seed0, keep1=None, keep2=None):
+def _draw(F, H1, H2, N3, x, rnd, seed0, keep1=None, keep2=None, cov=None):
     g = torch.Generator().manual_seed(seed0)
-    P = _params(g, F, H1, H2, N3)
-    q, out_r, zmin = _ref(P, x, rnd, keep1, keep2)
+    P = _params(g, F + (0 if cov is None else cov.shape[1]), H1, H2, N3)
+    q, out_r, zmin = _ref(P, x, rnd, keep1, keep2, cov)
     return g, P, q, out_r
 
 
@@ -222,5 +226,97 @@ def test_packed_pair_fused_adamw_matches_separate_weights():
         for a, b in zip(*res):
             for k in a:
                 assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), k
+    finally:
+        S.set_precision("fp32")
+
+
+@pytest.mark.parametrize("B,F,H1,H2,N3,C", [(1024, 2000, 900, 40, 40, 4), (130, 333, 16, 8, 0, 7), (257, 700, 800, 30, 1, 64),
+                                            (67, 516, 1024, 64, 64, 1)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_encoder_branch_with_covariates(B, F, H1, H2, N3, C, prec):
+    """The reference's default encoder input torch.cat([x, cov]) (model.py:128, cov=['labels'] is the constructor's
+    default): sparse x on the tile list, the covariate block as a dense [B, C] operand of the tail kernel, W1 = [H1, F + C].
+    Output and every gradient (the covariate columns of dW1 included) against the fp64 restatement."""
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision(prec)
+    try:
+        rng = np.random.default_rng(B + F + C)
+        m = _csr(rng, B + 3, F, 0.06)
+        rows = rng.permutation(B + 3)[:B]
+        x = torch.tensor(np.asarray(m[rows].todense(), dtype=np.float32))
+        gc = torch.Generator().manual_seed(C)
+        cov = torch.randn(B, C, generator=gc)
+        cov[:, 0] = (torch.rand(B, generator=gc) < 0.5).float()          # a one-hot-like column
+        rnd = (lambda t: t.bfloat16().double()) if prec == "bf16" else (lambda t: t.double())
+        g, P, q, out_r = _draw(F, H1, H2, N3, x, rnd, H1 + N3 + C, cov=cov)
+        wout = torch.randn(B, N3 if N3 else H2, generator=g)
+        (out_r * wout.double()).sum().backward()
+        d = {k: v.clone().to(DEV).requires_grad_(True) for k, v in P.items()}
+        tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), rows)
+        covd = cov.to(DEV)
+        assert ops.enc_branch_supported(tiles, covd, d["W1"], d["W2"], d.get("W3"), True, True)
+        spec = dict(d)
+        spec.setdefault("W3", None); spec.setdefault("b3", None)
+        out, = ops.enc_branches(tiles, [spec], 0.01, cov=covd)
+        (out * wout.to(DEV)).sum().backward()
+        rt = 2e-4 if prec == "fp32" else 2e-3
+        _check("out", out, out_r, rt)
+        for k in P:
+            assert d[k].grad is not None, k
+            if k == "W1":
+                _check("W1[:, :F]", d[k].grad[:, :F], q[k].grad[:, :F], rt * (10 if prec == "bf16" else 1))
+                _check("W1[:, F:]", d[k].grad[:, F:], q[k].grad[:, F:], rt)
+            else:
+                _check(k, d[k].grad, q[k].grad, rt)
+        with torch.no_grad():
+            out_e, = ops.enc_branches(tiles, [spec], 0.01, cov=covd)
+        assert torch.equal(out_e, out.detach())
+    finally:
+        S.set_precision("fp32")
+
+
+@pytest.mark.parametrize("C", [4, 8])
+def test_covariate_columns_fused_adamw_matches_separate_step(C):
+    """Packed pair of branches with a covariate block, precision 'bf16': two steps with the first layer's AdamW step
+    fused into the weight-gradient kernel (sparse columns) and into the tail's reduction (covariate columns) against the
+    same two steps through the plain gradient + multi-tensor AdamW: same parameters up to the hardware sqrt / rcp of the
+    fused update."""
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision("bf16")
+    try:
+        B, F, H1, H2 = 256, 600, 132, 16
+        rng = np.random.default_rng(9 + C)
+        m = _csr(rng, B, F, 0.1)
+        tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), np.arange(B))
+        x = torch.tensor(np.asarray(m.todense(), dtype=np.float32))
+        cov = torch.randn(B, C, generator=torch.Generator().manual_seed(3))
+        covd = cov.to(DEV)
+        res = []
+        for fuse in (False, True):
+            devs = []
+            for bi, N3 in enumerate((H2, 1)):
+                g, P, q, out_r = _draw(F, H1, H2, N3, x, lambda t: t.double(), 70 + bi, cov=cov)
+                devs.append({k: torch.nn.Parameter(v.clone().to(DEV)) for k, v in P.items()})
+            assert ops.pack_first_layers(devs[0]["W1"], devs[1]["W1"])
+            opt = S.FusedAdamW([{"params": [p for d in devs for p in d.values()], "weight_decay": 1e-2, "lr": 1e-2}])
+            if fuse:
+                opt.fuse_first_layer(devs[0]["W1"], devs[1]["W1"])
+            for _ in range(2):
+                opt.zero_grad()
+                outs = ops.enc_branches(tiles, devs, 0.01, cov=covd)
+                sum((o * o).sum() for o in outs).backward()
+                if fuse:
+                    assert devs[0]["W1"].grad is None and devs[1]["W1"].grad is None
+                opt.step()
+            res.append([{k: v.detach().clone() for k, v in d.items()} for d in devs])
+            # the bf16 shadow follows the master weights, covariate columns included
+            for d in devs:
+                sh = ops.shadow_of(d["W1"], create=False)
+                assert sh is not None and torch.equal(sh[:, :F + C].float(), d["W1"].detach().bfloat16().float())
+        for a, b in zip(*res):
+            for k in a:
+                assert torch.allclose(a[k], b[k], rtol=2e-5, atol=2e-6), (k, float((a[k] - b[k]).abs().max()))
     finally:
         S.set_precision("fp32")
