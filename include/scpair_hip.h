@@ -72,8 +72,10 @@ int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_ptr, const i
 /* The same weight gradient with the AdamW step of that weight (model.py:698-701, torch.optim.AdamW semantics as in
  * scp_adamw_multi) applied in the kernel's epilogue: W [N][ldw] fp32 master weights, exp_avg / exp_avg_sq (same
  * layout) and the bf16 shadow are updated in place and the gradient never reaches HBM.  For single-process training
- * (no gradient exchange between backward and the optimiser step).  Needs F % 4 == 0, ldw % 4 == 0, ld_bf16 % 4 == 0
- * and 16-byte aligned W / moments (SCP_ERR_SHAPE otherwise: use scp_spmm_dw_bf16 + scp_adamw_multi). */
+ * (no gradient exchange between backward and the optimiser step).  Only columns 0 .. F-1 of W are touched (ldw > F: a
+ * covariate block's weights or row padding behind them).  Needs ldw % 4 == 0, ld_bf16 % 4 == 0 and 16-byte aligned
+ * W / moments (SCP_ERR_SHAPE otherwise: use scp_spmm_dw_bf16 + scp_adamw_multi); rows that start on 128-byte boundaries
+ * (ldw % 32 == 0) stream at the full rate, others re-read the lines that feature tiles share. */
 int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,
                            const uint32_t* t_pk, const void* dYT, long ldt, float* W, long ldw, float* exp_avg, float* exp_avg_sq,
                            void* W_bf16, long ld_bf16, float lr, float weight_decay, float beta1, float beta2, float eps,
@@ -299,6 +301,8 @@ typedef struct {
   long g_bf16;       /* != 0: g points to bf16 gradients (n contiguous elements: the data-parallel exchange buffer
                         scp_spmm_dw_bf16_g16 writes and the all-reduce sums) instead of fp32 */
   const float* bc_dev; /* nullable: device words {bias_corr1, bias_corr2} read instead of the two values above */
+  long ld_p;         /* 0 or == cols: p, m, v are n contiguous elements; > cols: they are [n / cols][ld_p] (rows padded to
+                        128-byte boundaries) while g stays n contiguous elements */
 } ScpAdamTensor;
 int scp_adamw_multi(const ScpAdamTensor* tensors /* host array */, int n, float beta1, float beta2, float eps,
                     void* stream);

@@ -26,7 +26,7 @@ U64 = C.c_uint64
 class AdamTensor(C.Structure):
     _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("n", L),
                 ("lr", F), ("weight_decay", F), ("bias_corr1", F), ("bias_corr2", F), ("grad_scale", F),
-                ("p_bf16", P), ("cols", L), ("ld_bf16", L), ("g_bf16", L), ("bc_dev", P)]
+                ("p_bf16", P), ("cols", L), ("ld_bf16", L), ("g_bf16", L), ("bc_dev", P), ("ld_p", L)]
 
 
 class EncTail(C.Structure):

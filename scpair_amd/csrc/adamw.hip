@@ -47,23 +47,33 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
       }
     }
   };
+  // p / m / v index of gradient element i: the same, or (rows padded to ld_p elements) row * ld_p + column
+  const bool padded = t.ld_p > t.cols && t.cols > 0;
+  auto pidx = [&](long i) {
+    if (!padded) return i;
+    long rr = i / t.cols;
+    return rr * t.ld_p + (i - rr * t.cols);
+  };
+  if (padded) vec = vec && (t.cols & 3) == 0 && (t.ld_p & 3) == 0;   // a float4 never straddles a row
   if (vec && base + ADAM_CHUNK <= t.n) {
     // interior chunk: all 16 vector loads of the thread are issued before the first store (64 B x 4 streams in
     // flight per lane); the streams are read and written once, so they bypass the caches' retention (nontemporal)
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 p[4], g[4], m[4], v[4];
+    long pi[4];
 #pragma unroll
     for (int it = 0; it < 4; it++) {
       long i = base + (long)it * 1024 + threadIdx.x * 4;
-      p[it] = __builtin_nontemporal_load((const f4*)(t.p + i));
+      pi[it] = pidx(i);
+      p[it] = __builtin_nontemporal_load((const f4*)(t.p + pi[it]));
       if (g16) {
         bf16x4 gb = __builtin_nontemporal_load((const bf16x4*)(gh + i));
         g[it] = f4{(float)gb[0], (float)gb[1], (float)gb[2], (float)gb[3]};
       } else {
         g[it] = __builtin_nontemporal_load((const f4*)(t.g + i));
       }
-      m[it] = __builtin_nontemporal_load((const f4*)(t.m + i));
-      v[it] = __builtin_nontemporal_load((const f4*)(t.v + i));
+      m[it] = __builtin_nontemporal_load((const f4*)(t.m + pi[it]));
+      v[it] = __builtin_nontemporal_load((const f4*)(t.v + pi[it]));
     }
 #pragma unroll
     for (int it = 0; it < 4; it++) {
@@ -75,10 +85,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
         update(pa[k], g[it][k], ma[k], va[k]);
       }
       f4 po = {pa[0], pa[1], pa[2], pa[3]}, mo = {ma[0], ma[1], ma[2], ma[3]}, vo = {va[0], va[1], va[2], va[3]};
-      __builtin_nontemporal_store(po, (f4*)(t.p + i));
+      __builtin_nontemporal_store(po, (f4*)(t.p + pi[it]));
       if (t.p_bf16) shadow4(i, pa);
-      __builtin_nontemporal_store(mo, (f4*)(t.m + i));
-      __builtin_nontemporal_store(vo, (f4*)(t.v + i));
+      __builtin_nontemporal_store(mo, (f4*)(t.m + pi[it]));
+      __builtin_nontemporal_store(vo, (f4*)(t.v + pi[it]));
     }
     return;
   }
@@ -87,26 +97,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamPack pk) {
     long i = base + (long)it * 1024 + threadIdx.x * 4;
     if (i >= t.n) break;
     if (vec && i + 4 <= t.n) {
-      float4 p = *(float4*)(t.p + i), m = *(float4*)(t.m + i), v = *(float4*)(t.v + i);
+      const long q = pidx(i);
+      float4 p = *(float4*)(t.p + q), m = *(float4*)(t.m + q), v = *(float4*)(t.v + q);
       float pa[4] = {p.x, p.y, p.z, p.w}, ga[4] = {gload(i), gload(i + 1), gload(i + 2), gload(i + 3)}, ma[4] = {m.x, m.y, m.z, m.w},
             va[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; k++) update(pa[k], ga[k], ma[k], va[k]);
-      *(float4*)(t.p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+      *(float4*)(t.p + q) = make_float4(pa[0], pa[1], pa[2], pa[3]);
       if (t.p_bf16) shadow4(i, pa);
-      *(float4*)(t.m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
-      *(float4*)(t.v + i) = make_float4(va[0], va[1], va[2], va[3]);
+      *(float4*)(t.m + q) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+      *(float4*)(t.v + q) = make_float4(va[0], va[1], va[2], va[3]);
     } else {
       for (int k = 0; k < 4 && i + k < t.n; k++) {
-        float p = t.p[i + k], m = t.m[i + k], v = t.v[i + k];
+        const long q = pidx(i + k);
+        float p = t.p[q], m = t.m[q], v = t.v[q];
         update(p, gload(i + k), m, v);
-        t.p[i + k] = p;
+        t.p[q] = p;
         if (t.p_bf16) {
           long rr = (i + k) / t.cols, cc = (i + k) - rr * t.cols;
           ((__bf16*)t.p_bf16)[rr * t.ld_bf16 + cc] = (__bf16)p;
         }
-        t.m[i + k] = m;
-        t.v[i + k] = v;
+        t.m[q] = m;
+        t.v[q] = v;
       }
     }
   }
@@ -130,6 +142,8 @@ extern "C" int scp_adamw_multi(const ScpAdamTensor* tensors, int n, float beta1,
                 "scp_adamw_multi: bad bf16 shadow geometry in tensor %d", i);
       SCP_CHECK(t.bc_dev || (t.bias_corr1 > 0.f && t.bias_corr2 > 0.f), SCP_ERR_ARG,
                 "scp_adamw_multi: bias corrections must be > 0");
+      SCP_CHECK(t.ld_p == 0 || (t.cols > 0 && t.ld_p >= t.cols && t.n % t.cols == 0), SCP_ERR_ARG,
+                "scp_adamw_multi: padded rows need cols > 0, ld_p >= cols and n a multiple of cols (tensor %d)", i);
       if (t.n == 0) continue;
       pk.t[pk.n] = t;
       pk.chunk_start[pk.n] = chunks;

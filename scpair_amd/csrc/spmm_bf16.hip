@@ -533,16 +533,16 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
     const AdamHyper hy = adam_hyper(g.lr, g.wd, g.b1, g.b2, g.eps, bc1, bc2, g.gscale);
     const int c4 = (tid & 63) * 4, rw = tid >> 6;   // one wave per 1 KB row segment, 8 rows per pass
     const int n = n0 + c4;
-    const bool col_ok = n + 4 <= g.F;               // F % 4 == 0 (host-checked): a float4 is all in or all out
+    const bool col_ok = n + 4 <= g.F;               // a float4 that straddles column F (F % 4 != 0) takes the scalar path below
 #pragma unroll 1
     for (int pass = 0; pass < 16; pass += EPB) {
       // EPB row segments of the three streams in flight per lane before the first use: with one workgroup per CU the
       // epilogue's HBM rate is set by the bytes each CU keeps outstanding
       f4 pp[EPB], mm[EPB], vv[EPB];
-      // unpredicated (rows / columns past the end read a clamped, valid address; only the stores are predicated): the
-      // loads and the updates below form one straight line, so each row is processed when ITS loads have landed
-      // (counted waits) instead of after all of them
-      const int nc = col_ok ? n : max(g.F - 4, 0);
+      // unpredicated (rows / columns past the end read a clamped, valid, 16-byte aligned address; only the stores are
+      // predicated): the loads and the updates below form one straight line, so each row is processed when ITS loads
+      // have landed (counted waits) instead of after all of them
+      const int nc = col_ok ? n : max((g.F & ~3) - 4, 0);
 #pragma unroll
       for (int u = 0; u < EPB; u++) {
         const int m = min(m0 + (pass + u) * 8 + rw, g.N - 1);
@@ -572,6 +572,18 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
 #pragma unroll
           for (int k = 0; k < 4; k++) sh[k] = (__bf16)pa[k];
           *(bf16x4*)(g.adam_sh + (long)m * g.adam_ldsh + n) = sh;
+        } else if (n < g.F && m < g.N) {
+          // the last columns of a feature count that is no multiple of 4: element by element (one lane per row); the
+          // columns behind F are not this kernel's (a covariate block's weights, or padding)
+          for (int k = 0; n + k < g.F; k++) {
+            const long o = (long)m * g.ldc + n + k;
+            float p_ = g.C[o], m_ = g.adam_m[o], v_ = g.adam_v[o];
+            adamw_update_fast(hy, p_, gg[k], m_, v_);
+            g.C[o] = p_;
+            g.adam_m[o] = m_;
+            g.adam_v[o] = v_;
+            g.adam_sh[(long)m * g.adam_ldsh + n + k] = (__bf16)p_;
+          }
         }
       }
     }
@@ -812,16 +824,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     const AdamHyper hy = adam_hyper(g.lr, g.wd, g.b1, g.b2, g.eps, bc1, bc2, g.gscale);
     const int c4 = (tid & 31) * 4, rw = tid >> 5;   // half a wave per 512 B row segment, 8 rows per pass
     const int n = n0 + c4;
-    const bool col_ok = n + 4 <= g.F;               // F % 4 == 0 (host-checked): a float4 is all in or all out
+    const bool col_ok = n + 4 <= g.F;               // a float4 that straddles column F (F % 4 != 0) takes the scalar path below
 #pragma unroll 1
     for (int pass = 0; pass < 16; pass += EPB) {
       // EPB row segments of the three streams in flight per lane before the first use: with one workgroup per CU the
       // epilogue's HBM rate is set by the bytes each CU keeps outstanding
       f4 pp[EPB], mm[EPB], vv[EPB];
-      // unpredicated (rows / columns past the end read a clamped, valid address; only the stores are predicated): the
-      // loads and the updates below form one straight line, so each row is processed when ITS loads have landed
-      // (counted waits) instead of after all of them
-      const int nc = col_ok ? n : max(g.F - 4, 0);
+      // unpredicated (rows / columns past the end read a clamped, valid, 16-byte aligned address; only the stores are
+      // predicated): the loads and the updates below form one straight line, so each row is processed when ITS loads
+      // have landed (counted waits) instead of after all of them
+      const int nc = col_ok ? n : max((g.F & ~3) - 4, 0);
 #pragma unroll
       for (int u = 0; u < EPB; u++) {
         const int m = min(m0 + (pass + u) * 8 + rw, g.N - 1);
@@ -851,6 +863,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma unroll
           for (int k = 0; k < 4; k++) sh[k] = (__bf16)pa[k];
           *(bf16x4*)(g.adam_sh + (long)m * g.adam_ldsh + n) = sh;
+        } else if (n < g.F && m < g.N) {
+          // the last columns of a feature count that is no multiple of 4: element by element (one lane per row); the
+          // columns behind F are not this kernel's (a covariate block's weights, or padding)
+          for (int k = 0; n + k < g.F; k++) {
+            const long o = (long)m * g.ldc + n + k;
+            float p_ = g.C[o], m_ = g.adam_m[o], v_ = g.adam_v[o];
+            adamw_update_fast(hy, p_, gg[k], m_, v_);
+            g.C[o] = p_;
+            g.adam_m[o] = m_;
+            g.adam_v[o] = v_;
+            g.adam_sh[(long)m * g.adam_ldsh + n + k] = (__bf16)p_;
+          }
         }
       }
     }
@@ -1022,9 +1046,9 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
             "scp_spmm_dw_adamw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
   SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: more than %d cells per call unsupported",
             64 * (PCH + 1));
-  SCP_CHECK(F % 4 == 0 && ldw % 4 == 0 && ldw >= F && ld_bf16 % 4 == 0 && ld_bf16 >= F &&
+  SCP_CHECK(ldw % 4 == 0 && ldw >= F && ldw >= 4 && ld_bf16 % 4 == 0 && ld_bf16 >= F &&
                 (((uintptr_t)W | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) == 0 && ((uintptr_t)W_bf16 % 8) == 0,
-            SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: needs F %% 4 == 0, leading dimensions %% 4 == 0 and 16-byte aligned W / moments");
+            SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: needs leading dimensions %% 4 == 0 and 16-byte aligned W / moments");
   SCP_CHECK(bc_dev || (bias_corr1 > 0.f && bias_corr2 > 0.f), SCP_ERR_ARG,
             "scp_spmm_dw_adamw_bf16: bias corrections must be > 0");
   static uint64_t done_v = 0, done_n = 0;

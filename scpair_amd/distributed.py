@@ -71,6 +71,11 @@ class GradSync:
     def broadcast(self, tensors, src=0):
         for t in tensors:
             t = t.data if hasattr(t, "data") else t
+            if not t.is_contiguous():                      # row-padded first-layer weights (ops.home_first_layers)
+                c = t.contiguous()
+                self.broadcast([c], src=src)
+                t.copy_(c)
+                continue
             if self._backend != "nccl" and t.is_cuda:      # staged through host like the other gloo + GPU collectives
                 h = t.detach().cpu()
                 dist.broadcast(h, src=src, group=self.group)

@@ -88,16 +88,24 @@ import weakref
 _shadows = {}          # id(W) -> (weakref(W), shadow, version); tensors compare element-wise, so no WeakKeyDictionary
 
 
+def row_ld(W):
+    """Row stride (elements) of a 2-D weight whose rows are contiguous -- W itself contiguous, or a row-padded view
+    made by home_first_layers -- else None."""
+    if W.ndim != 2 or W.stride(1) != 1 or W.stride(0) < W.shape[1]:
+        return None
+    return W.stride(0)
+
+
 def shadow_of(W, create=True):
-    """bf16 copy [H, ld] (ld = cols rounded up to 8, zero padded) of a 2-D fp32 weight, for the bf16 first-layer
-    kernels.  It is refreshed here whenever torch has modified W (version counter) and rewritten by FusedAdamW
-    in the same kernel that updates W, so it never lags the master weights."""
+    """bf16 copy [H, ld] (ld = cols rounded up to 64: rows start on 128-byte boundaries; zero padded) of a 2-D fp32
+    weight, for the bf16 first-layer kernels.  It is refreshed here whenever torch has modified W (version counter) and
+    rewritten by FusedAdamW in the same kernel that updates W, so it never lags the master weights."""
     ent = _shadows.get(id(W))
     if ent is not None and ent[0]() is not W:          # id reused by another tensor
         ent = None
     else:
-        ent = None if ent is None else (ent[1], ent[2])
-    if ent is not None and ent[1] == W._version and ent[0].device == W.device:
+        ent = None if ent is None else (ent[1], ent[2], ent[3])
+    if ent is not None and ent[1] == W._version and ent[2] == W.data_ptr() and ent[0].device == W.device:
         return ent[0]
     if not create:
         return None
@@ -106,22 +114,22 @@ def shadow_of(W, create=True):
             del _shadows[k]
     L = _lib.lib()
     H, cols = W.shape
-    ld = (cols + 7) // 8 * 8
-    if ent is not None and ent[0].shape == (H, ld) and ent[0].device == W.device:
+    ld = (cols + 63) // 64 * 64
+    pk, off = _pack_of(W)
+    if pk is not None and pk[1].device == W.device:   # homed weights: adjacent row blocks of one shadow
+        if pk[2]["shadow"] is None or pk[2]["shadow"].shape != (pk[1].shape[0], ld) or pk[2]["shadow"].device != W.device:
+            pk[2]["shadow"] = torch.empty((pk[1].shape[0], ld), dtype=torch.bfloat16, device=W.device)
+        sh = pk[2]["shadow"][off:off + H]
+    elif ent is not None and ent[0].shape == (H, ld) and ent[0].device == W.device:
         sh = ent[0]
     else:
-        pk, off = _pack_of(W)
-        if pk is not None and pk[2].device == W.device:   # packed pair: adjacent row blocks of one shadow
-            if pk[3]["shadow"] is None or pk[3]["shadow"].shape != (pk[2].shape[0], ld) or pk[3]["shadow"].device != W.device:
-                pk[3]["shadow"] = torch.empty((pk[2].shape[0], ld), dtype=torch.bfloat16, device=W.device)
-            sh = pk[3]["shadow"][off:off + H]
-        else:
-            sh = torch.empty((H, ld), dtype=torch.bfloat16, device=W.device)
+        sh = torch.empty((H, ld), dtype=torch.bfloat16, device=W.device)
     Wc = W.detach()
-    if not Wc.is_contiguous():
-        raise RuntimeError("first-layer weights must be contiguous")
-    _lib.check(L.scp_cast_bf16(Wc.data_ptr(), H, cols, cols, sh.data_ptr(), ld, _lib.stream()), "scp_cast_bf16")
-    _shadows[id(W)] = (weakref.ref(W), sh, W._version)
+    ldw = row_ld(Wc)
+    if ldw is None:
+        raise RuntimeError("first-layer weights must have contiguous rows")
+    _lib.check(L.scp_cast_bf16(Wc.data_ptr(), H, cols, ldw, sh.data_ptr(), ld, _lib.stream()), "scp_cast_bf16")
+    _shadows[id(W)] = (weakref.ref(W), sh, W._version, W.data_ptr())
     return sh
 
 
@@ -320,9 +328,10 @@ class FcnnLayerFn(torch.autograd.Function):
         step of W runs inside the weight-gradient kernel (or None)."""
         L = _lib.lib()
         sparse = isinstance(x, BatchTiles)
-        Wc = _f32c(W)
+        Wc = W if (W.dtype == torch.float32 and row_ld(W) is not None) else _f32c(W)   # contiguous or row-padded (homed)
         _lib.require_cuda(Wc, cov, None if sparse else x)
         H, Ftot = Wc.shape
+        ldw = row_ld(Wc)
         Bn, F = x.shape
         C_ = 0 if cov is None else cov.shape[1]
         if F + C_ != Ftot:
@@ -345,15 +354,15 @@ class FcnnLayerFn(torch.autograd.Function):
             xs = None
         elif sparse:
             _lib.check(L.scp_spmm_fwd(Bn, H, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), Wc.data_ptr(),
-                                      Ftot, slabs.data_ptr(), H, None, nsplit, ns, _lib.stream()), "scp_spmm_fwd")
+                                      ldw, slabs.data_ptr(), H, None, nsplit, ns, _lib.stream()), "scp_spmm_fwd")
             xs = None
         else:
             xs = _f32c(x)
-            gemm_nt(Bn, H, F, xs, F, 1, Wc, Ftot, 1, slabs, H, nsplit=nsplit, ns=ns)
+            gemm_nt(Bn, H, F, xs, F, 1, Wc, ldw, 1, slabs, H, nsplit=nsplit, ns=ns)
         covc = None
         if C_:
             covc = _f32c(cov)
-            gemm_nt(Bn, H, C_, covc, C_, 1, Wc, Ftot, 1, slabs, H, ns=ns, b_off=F, c_off=nsplit * Bn * H)
+            gemm_nt(Bn, H, C_, covc, C_, 1, Wc, ldw, 1, slabs, H, ns=ns, b_off=F, c_off=nsplit * Bn * H)
         out = torch.empty((Bn, H), dtype=torch.float32, device=dev)
         xhat = torch.empty((Bn, H), dtype=torch.float32, device=dev)
         rstd = torch.empty((Bn,), dtype=torch.float32, device=dev)
@@ -368,7 +377,7 @@ class FcnnLayerFn(torch.autograd.Function):
         ctx.cfg = (slope, p_drop, seed, Bn, H, F, C_, ns, b is not None)
         ctx.seed_dev = seed_dev
         ctx.use_bf = use_bf
-        ctx.fused = fused if (use_bf and C_ == 0 and Ftot % 4 == 0) else None
+        ctx.fused = fused if (use_bf and C_ == 0 and ldw % 4 == 0) else None
         ctx.sink = sink if (use_bf and C_ == 0 and ctx.fused is None) else None
         return out
 
@@ -402,12 +411,14 @@ class FcnnLayerFn(torch.autograd.Function):
                     # weight gradient + AdamW step of W in one kernel: dW never reaches HBM, autograd gets no gradient
                     m_, v_, sh_, hp = ctx.fused.begin_step(W)
                     dW = None
+                    if row_ld(m_) != row_ld(W) or row_ld(v_) != row_ld(W):
+                        raise RuntimeError("fused first layer: AdamW moments and weights differ in layout")
                     tm = _cfg["fused_timer"]
                     if tm is not None:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                     _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, H, F, _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), _lib.ptr(t.pk),
-                                                        dYT.data_ptr(), ldt, W.data_ptr(), Ftot, m_.data_ptr(),
+                                                        dYT.data_ptr(), ldt, W.data_ptr(), row_ld(W), m_.data_ptr(),
                                                         v_.data_ptr(), sh_.data_ptr(), sh_.shape[1], *hp,
                                                         _lib.stream()), "scp_spmm_dw_adamw_bf16")
                     if tm is not None:
@@ -437,13 +448,13 @@ class FcnnLayerFn(torch.autograd.Function):
                 gemm_nt(H, C_, Bn, dY, 1, H, cov, 1, C_, dW, Ftot, ns=ns, c_off=F)
         if (not ctx.sparse) and ctx.needs_input_grad[0]:
             dx = torch.empty((Bn, F), dtype=torch.float32, device=dev)
-            gemm_nt_auto(Bn, F, H, dY, H, 1, W, 1, Ftot, dx, ns=ns)
+            gemm_nt_auto(Bn, F, H, dY, H, 1, W, 1, row_ld(W), dx, ns=ns)
         return dx, None, dW, dbias, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
     shadow = fused = sink = None
-    if isinstance(x, BatchTiles) and _ns() == 1 and W.is_cuda and W.dtype == torch.float32 and W.is_contiguous():
+    if isinstance(x, BatchTiles) and _ns() == 1 and W.is_cuda and W.dtype == torch.float32 and row_ld(W) is not None:
         shadow = shadow_of(W)
         if cov is None and torch.is_grad_enabled() and W.requires_grad:
             fused = fused_handle(W)
@@ -459,72 +470,137 @@ def fcnn_layer(x, cov, W, b, gamma, beta, slope, p_drop=0.0, seed=0, eps=1e-5):
 # Two branches whose first-layer weights are packed (pack_first_layers) run their first-layer product, its weight
 # gradient and the AdamW step as ONE launch each over the [H1a + H1b, F] weight block.
 # ------------------------------------------------------------------------------------------------
-_packs = {}            # id(Wa) -> (weakref(Wa), weakref(Wb), cat, {"shadow": bf16 [Ha+Hb, ld] or None})
+_packs = {}            # id(first weight) -> ([weakref(W), ...], block [sum H, ld], {"shadow": bf16 [sum H, lds] or None})
 
 
 def _pack_of(W):
-    """(pack entry, row offset) of a first-layer weight that is one of a packed pair, else (None, 0)."""
+    """(home entry, row offset) of a first-layer weight that lives in a block made by home_first_layers, else (None, 0)."""
     for ent in _packs.values():
-        a, b = ent[0](), ent[1]()
-        if a is W:
-            return ent, 0
-        if b is W and a is not None:
-            return ent, a.shape[0]
+        off = 0
+        ws = [r() for r in ent[0]]
+        if any(w is None for w in ws):
+            continue
+        for w in ws:
+            if w is W:
+                return (ent, off) if _homed_ok(ent, ws) else (None, 0)
+            off += w.shape[0]
     return None, 0
+
+
+def _homed_ok(ent, ws):
+    """Every weight of the entry still is the view of the block it was made (load_state_dict and optimiser steps write in
+    place and keep it so; `.data = ...` assignments by the user do not)."""
+    block = ent[1]
+    off = 0
+    for w in ws:
+        if w.data_ptr() != block.data_ptr() + 4 * off * block.shape[1] or w.stride(0) != block.shape[1] or w.device != block.device:
+            return False
+        off += w.shape[0]
+    return True
 
 
 def _rows_adjacent(a, b, row_bytes):
     return b.data_ptr() == a.data_ptr() + a.shape[0] * row_bytes
 
 
-def pack_first_layers(Wa, Wb):
-    """Make two first-layer weights of the same input (fp32, [Ha, F] and [Hb, F], on the GPU) adjacent row blocks of one
-    [Ha + Hb, F] tensor (their .data become views of it; values, shapes and Parameter identity are unchanged), so the
-    bf16 first-layer kernels treat the two branches as one layer.  Idempotent; returns False when the pair cannot be
-    packed.  Optimiser state and bf16 shadows created afterwards are packed the same way."""
-    if Wa is Wb or Wa.ndim != 2 or Wb.ndim != 2 or Wa.shape[1] != Wb.shape[1] or not (Wa.is_cuda and Wb.is_cuda) \
-            or Wa.device != Wb.device or Wa.dtype != torch.float32 or Wb.dtype != torch.float32 \
-            or (Wa.shape[0] * Wa.shape[1]) % 4 or not (Wa.is_contiguous() and Wb.is_contiguous()):
+def home_first_layers(*Ws):
+    """Give one first-layer weight -- or the weights of the branches of one encoder, which see the same input (fp32,
+    [H_i, F] each, on the GPU) -- the storage the bf16 first-layer kernels stream best: adjacent row blocks of ONE
+    [sum H_i, ld] tensor whose rows start on 128-byte boundaries (ld = F rounded up to 32 floats, pad columns zero).  The
+    parameters' .data become views [:, :F] of it: values, shapes, names and Parameter identity are unchanged, state_dict /
+    load_state_dict / torch.save work as before; only .stride(0) may differ from F.  With adjacent blocks the kernels treat
+    the branches as one layer (one product, one weight-gradient + AdamW launch); with aligned rows the AdamW epilogue
+    touches whole cache lines (an odd F, or a covariate block behind the features, otherwise costs ~30 % of its rate).
+    Idempotent; returns False when the weights cannot be homed.  Optimiser state and bf16 shadows created afterwards
+    follow the same layout."""
+    if not 1 <= len(Ws) <= ENC_MAX_BRANCHES or len(set(id(w) for w in Ws)) != len(Ws):
         return False
-    F = Wa.shape[1]
-    ent = _packs.get(id(Wa))
-    if ent is not None and ent[0]() is Wa and ent[1]() is Wb and _rows_adjacent(Wa, Wb, 4 * F) \
-            and Wa.data_ptr() == ent[2].data_ptr():
-        return True
-    for k in [k for k, v in _packs.items() if v[0]() is None or v[1]() is None]:
+    W0 = Ws[0]
+    for w in Ws:
+        if w.ndim != 2 or w.shape[1] != W0.shape[1] or not w.is_cuda or w.device != W0.device or w.dtype != torch.float32 \
+                or row_ld(w) is None:
+            return False
+    F = W0.shape[1]
+    ld = (F + 31) // 32 * 32
+    ent = _packs.get(id(W0))
+    if ent is not None:
+        ws = [r() for r in ent[0]]
+        if len(ws) == len(Ws) and all(a is b for a, b in zip(ws, Ws)) and ent[1].shape[1] == ld and _homed_ok(ent, ws):
+            return True
+    for k in [k for k, v in _packs.items() if any(r() is None for r in v[0])]:
         del _packs[k]
-    Ha, Hb = Wa.shape[0], Wb.shape[0]
+    for w in Ws:                                       # a weight moves out of the home it had (e.g. a pair re-homed alone)
+        for k in [k for k, v in _packs.items() if any(r() is w for r in v[0])]:
+            del _packs[k]
+    Hs = [w.shape[0] for w in Ws]
     with torch.no_grad():
-        cat = torch.empty((Ha + Hb, F), dtype=torch.float32, device=Wa.device)
-        cat[:Ha].copy_(Wa)
-        cat[Ha:].copy_(Wb)
-        Wa.data = cat[:Ha]
-        Wb.data = cat[Ha:]
-    _shadows.pop(id(Wa), None)
-    _shadows.pop(id(Wb), None)
-    _packs[id(Wa)] = (weakref.ref(Wa), weakref.ref(Wb), cat, {"shadow": None})
+        block = torch.empty((sum(Hs), ld), dtype=torch.float32, device=W0.device)
+        if ld > F:
+            block[:, F:].zero_()
+        off = 0
+        for w, h in zip(Ws, Hs):
+            block[off:off + h, :F].copy_(w)
+            w.data = block[off:off + h, :F]
+            off += h
+    for w in Ws:
+        _shadows.pop(id(w), None)
+    _packs[id(W0)] = ([weakref.ref(w) for w in Ws], block, {"shadow": None})
     return True
 
 
+def ensure_homed(W):
+    """home_first_layers(W) unless W already lives in a home (alone or with the other branches of its encoder)."""
+    if _pack_of(W)[0] is not None:
+        return True
+    return home_first_layers(W)
+
+
+def pack_first_layers(Wa, Wb):
+    """home_first_layers for the two branches of one encoder (hidden_rep and hidden_lib, model.py:77-92)."""
+    return home_first_layers(Wa, Wb)
+
+
 def _new_adam_state(opt, p):
-    """Fresh AdamW state of p; the two weights of a packed pair get adjacent moments (one [Ha+Hb, F] block each)."""
+    """Fresh AdamW state of p; homed weights get moments of the same layout (one [sum H, ld] block each for the weights
+    of one home, pad columns zero and never touched)."""
     ent, off = _pack_of(p)
     if ent is not None:
-        a, b = ent[0](), ent[1]()
-        if a is not None and b is not None and len(opt.state[a]) == 0 and len(opt.state[b]) == 0 \
-                and _rows_adjacent(a, b, 4 * a.shape[1]):
-            m = torch.zeros((a.shape[0] + b.shape[0], a.shape[1]), dtype=torch.float32, device=a.device)
-            v = torch.zeros_like(m)
-            for q, lo in ((a, 0), (b, a.shape[0])):
+        ws = [r() for r in ent[0]]
+        if all(len(opt.state[w]) == 0 for w in ws):
+            block = ent[1]
+            m = torch.zeros_like(block)
+            v = torch.zeros_like(block)
+            lo = 0
+            for q in ws:
                 st = opt.state[q]
                 st["step"] = 0
-                st["exp_avg"] = m[lo:lo + q.shape[0]]
-                st["exp_avg_sq"] = v[lo:lo + q.shape[0]]
+                st["exp_avg"] = m[lo:lo + q.shape[0], :q.shape[1]]
+                st["exp_avg_sq"] = v[lo:lo + q.shape[0], :q.shape[1]]
+                lo += q.shape[0]
             return
     st = opt.state[p]
     st["step"] = 0
-    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+    if p.is_contiguous():
+        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+    else:                                              # row-padded view whose home is gone: same strides
+        ld = row_ld(p)
+        if ld is None:
+            raise RuntimeError("FusedAdamW needs parameters with contiguous rows")
+        st["exp_avg"] = torch.zeros((p.shape[0], ld), dtype=p.dtype, device=p.device)[:, :p.shape[1]]
+        st["exp_avg_sq"] = torch.zeros((p.shape[0], ld), dtype=p.dtype, device=p.device)[:, :p.shape[1]]
+
+
+def _relayout_state(st, p):
+    """Moments created before p was homed (or after its home was dropped): copy them into p's row layout."""
+    ld = row_ld(p)
+    if ld is None:
+        raise RuntimeError("FusedAdamW needs parameters with contiguous rows")
+    for k in ("exp_avg", "exp_avg_sq"):
+        if row_ld(st[k]) != ld:
+            t = torch.zeros((p.shape[0], ld), dtype=p.dtype, device=p.device)[:, :p.shape[1]]
+            t.copy_(st[k])
+            st[k] = t
 
 
 ENC_MAX_BRANCHES = 4
@@ -544,8 +620,10 @@ def enc_branch_supported(x, cov, W1, W2, W3, ln1, ln2):
     H1, H2 = W1.shape[0], W2.shape[0]
     if H1 % 4 or H1 > 1024 or H2 > 64 or W2.shape[1] != H1 or (W3 is not None and (W3.shape[0] > 64 or W3.shape[1] != H2)):
         return False
+    if not (W1.is_cuda and W1.dtype == torch.float32 and row_ld(W1) is not None and W1.data_ptr() % 16 == 0):
+        return False                                   # W1: contiguous, or a row-padded view (home_first_layers)
     return all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0)
-               for t in (W1, W2, W3))
+               for t in (W2, W3))
 
 
 def _carve(sizes, dev):
@@ -581,10 +659,11 @@ class EncBranchesFn(torch.autograd.Function):
             if p_[0].shape[1] != Ft:
                 raise ValueError(f"encoder: first layer expects {p_[0].shape[1]} inputs, the minibatch has {F} features"
                                  f" (+{Cn} covariates)")
+        ldws = [row_ld(p_[0]) for p_ in P]             # row strides of the first-layer weights (Ft, or padded: homed)
         shadows = [b_["shadow"] for b_ in cfg["br"]]
         use_bf = ns == 1 and all(sh is not None for sh in shadows)
         # one first-layer launch for both branches when their weights (and bf16 shadows) are adjacent row blocks
-        merged = (nb == 2 and use_bf and _rows_adjacent(P[0][0], P[1][0], 4 * Ft)
+        merged = (nb == 2 and use_bf and ldws[0] == ldws[1] and _rows_adjacent(P[0][0], P[1][0], 4 * ldws[0])
                   and shadows[0].shape[1] == shadows[1].shape[1]
                   and _rows_adjacent(shadows[0], shadows[1], 2 * shadows[0].shape[1]))
         groups = [list(range(nb))] if merged else [[i] for i in range(nb)]
@@ -622,8 +701,8 @@ class EncBranchesFn(torch.autograd.Function):
                                                sh.shape[1], slabs[gi].data_ptr(), Hg, nsplits[gi], stream),
                            "scp_spmm_fwd_bf16")
             else:
-                _lib.check(L.scp_spmm_fwd(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(), Ft,
-                                          slabs[gi].data_ptr(), Hg, None, nsplits[gi], ns, stream), "scp_spmm_fwd")
+                _lib.check(L.scp_spmm_fwd(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(),
+                                          ldws[g[0]], slabs[gi].data_ptr(), Hg, None, nsplits[gi], ns, stream), "scp_spmm_fwd")
             col = 0
             for i in g:
                 slab_of[i] = (slabs[gi].data_ptr() + 4 * col, Bn * Hg, Hg, nsplits[gi])
@@ -647,14 +726,14 @@ class EncBranchesFn(torch.autograd.Function):
             m.out, m.ldo = outs[i].data_ptr(), nouts[i]
             if Cn:
                 m.cov, m.ldcov, m.C = cov.data_ptr(), Cn, Cn
-                m.W1c, m.ldw1c = W1.data_ptr() + 4 * F, Ft
+                m.W1c, m.ldw1c = W1.data_ptr() + 4 * F, ldws[i]
         _lib.check(L.scp_enc_tail_fwd(arr, nb, stream), "scp_enc_tail_fwd")
         if train:
             ctx.arr, ctx.tiles, ctx.buf, ctx.cfg = arr, x, buf, cfg
             ctx.cov = cov
             ctx.save_for_backward(*[t for t in tensors if t is not None])
             ctx.present = [t is not None for t in tensors]
-            ctx.dims = (Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn)
+            ctx.dims = (Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn, ldws)
         return tuple(outs)
 
     @staticmethod
@@ -662,7 +741,7 @@ class EncBranchesFn(torch.autograd.Function):
         L = _lib.lib()
         it = iter(ctx.saved_tensors)
         tensors = [next(it) if pr else None for pr in ctx.present]
-        Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn = ctx.dims
+        Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn, ldws = ctx.dims
         Ft = F + Cn
         nb = len(H1s)
         P = [tensors[10 * i:10 * i + 10] for i in range(nb)]
@@ -697,8 +776,8 @@ class EncBranchesFn(torch.autograd.Function):
                 if need_w1[i]:
                     plan.append(([i], "plain32", torch.empty((H1s[i], Ft), dtype=torch.float32, device=dev)))
         else:
-            fuse_ok = F % 4 == 0 and Ft % 4 == 0
             for g in groups:
+                fuse_ok = ldws[g[0]] % 4 == 0          # rows of W / moments 16-byte aligned (any F: homed weights are)
                 if not any(need_w1[i] for i in g):
                     continue
                 units = [g]
@@ -765,6 +844,8 @@ class EncBranchesFn(torch.autograd.Function):
                         st_i = fz_i.opt.state[p_i]
                         sh_i = shadow_of(p_i)
                         lr, wd, b1_, b2_, eps_, bc1, bc2, gs, bc_dev = payload[3]
+                        if row_ld(st_i["exp_avg"]) != ldws[i] or row_ld(st_i["exp_avg_sq"]) != ldws[i]:
+                            raise RuntimeError("fused first layer: AdamW moments and weights differ in layout")
                         m.adam = 1
                         m.adam_m, m.adam_v = st_i["exp_avg"].data_ptr() + 4 * F, st_i["exp_avg_sq"].data_ptr() + 4 * F
                         m.adam_sh, m.adam_ldsh = sh_i.data_ptr() + 2 * F, sh_i.shape[1]
@@ -793,7 +874,9 @@ class EncBranchesFn(torch.autograd.Function):
                 if tm is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, W1.data_ptr(), Ft,
+                if row_ld(m_) != ldws[u[0]] or row_ld(v_) != ldws[u[0]]:
+                    raise RuntimeError("fused first layer: AdamW moments and weights differ in layout")
+                _lib.check(L.scp_spmm_dw_adamw_bf16(Bn, Hu, F, tp, tk, tv, tpk, dyt_ptr, ldt, W1.data_ptr(), ldws[u[0]],
                                                     m_.data_ptr(), v_.data_ptr(), sh_.data_ptr(), sh_.shape[1],
                                                     *hp, stream), "scp_spmm_dw_adamw_bf16")
                 if tm is not None:
@@ -829,9 +912,11 @@ def _fused_pair_ok(fa, fb, Wa, Wb):
     sa, sb = opt.state[pa], opt.state[pb]
     if len(sa) == 0 or len(sb) == 0 or sa["step"] != sb["step"]:
         return False
-    F = Wa.shape[1]
+    ld = row_ld(Wa)
+    if ld is None or any(row_ld(t) != ld for t in (Wb, sa["exp_avg"], sb["exp_avg"], sa["exp_avg_sq"], sb["exp_avg_sq"])):
+        return False
     sha, shb = shadow_of(pa), shadow_of(pb)
-    return (_rows_adjacent(sa["exp_avg"], sb["exp_avg"], 4 * F) and _rows_adjacent(sa["exp_avg_sq"], sb["exp_avg_sq"], 4 * F)
+    return (_rows_adjacent(sa["exp_avg"], sb["exp_avg"], 4 * ld) and _rows_adjacent(sa["exp_avg_sq"], sb["exp_avg_sq"], 4 * ld)
             and sha.shape[1] == shb.shape[1] and _rows_adjacent(sha, shb, 2 * sha.shape[1]))
 
 
@@ -1409,6 +1494,8 @@ class FusedFirstLayer:
         st = opt.state[p]
         if len(st) == 0:
             _new_adam_state(opt, p)
+        if row_ld(st["exp_avg"]) != row_ld(p) or row_ld(st["exp_avg_sq"]) != row_ld(p):
+            _relayout_state(st, p)
         t = st["step"] + 1
         b1, b2 = self.group["betas"]
         sh = shadow_of(p)
@@ -1476,7 +1563,7 @@ def fused_handle(W):
 
 import struct as _struct
 
-_ADAM_FMT = _struct.Struct("@PPPPqfffffPqqqP")     # ScpAdamTensor, packed without building ctypes objects per tensor
+_ADAM_FMT = _struct.Struct("@PPPPqfffffPqqqPq")     # ScpAdamTensor, packed without building ctypes objects per tensor
 assert _ADAM_FMT.size == C.sizeof(_lib.AdamTensor)
 
 
@@ -1617,8 +1704,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 pptr = p.data_ptr()
                 if checked.get(id(p)) != pptr:                  # device / layout checks once per (parameter, storage)
                     _lib.require_cuda(p)
-                    if not p.is_contiguous():
-                        raise RuntimeError("FusedAdamW needs contiguous parameters")
+                    if not p.is_contiguous() and (p.ndim != 2 or row_ld(p) is None):
+                        raise RuntimeError("FusedAdamW needs contiguous parameters (or row-padded 2-D weights)")
                     checked[id(p)] = pptr
                 st = self.state[p]
                 if len(st) == 0:
@@ -1636,9 +1723,14 @@ class FusedAdamW(torch.optim.Optimizer):
                 buf, n = ent
                 if (n + 1) * fmt.size > len(buf):
                     buf.extend(bytes(len(buf)))
+                ld_p = 0
+                if p.ndim == 2 and p.stride(0) != p.shape[1]:   # row-padded weight: moments share its layout
+                    ld_p = p.stride(0)
+                    if st["exp_avg"].stride(0) != ld_p or st["exp_avg_sq"].stride(0) != ld_p:
+                        _relayout_state(st, p)
                 fmt.pack_into(buf, n * fmt.size, pptr, g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                               p.numel(), lr, wd, bc1, bc2, grad_scale, 0 if sh is None else sh.data_ptr(), p.shape[-1],
-                              0 if sh is None else sh.shape[1], g16, bc_dev)
+                              0 if sh is None else sh.shape[1], g16, bc_dev, ld_p)
                 ent[1] = n + 1
                 keep.append(g)
                 if g16:

@@ -67,6 +67,8 @@ class HipFCNN(nn.Sequential):
         for gi, (lin, ln, act, bn, drop) in enumerate(self._groups()):
             p = float(drop.p) if (self.training and drop.p > 0) else 0.0
             fused_p = 0.0 if bn is not None else p
+            if gi == 0 and isinstance(x, ops.BatchTiles) and lin.weight.is_cuda and ops.get_precision() == "bf16":
+                ops.ensure_homed(lin.weight)            # rows on 128-byte boundaries for the bf16 first-layer kernels
             x = ops.fcnn_layer(x, cov if gi == 0 else None, lin.weight, lin.bias,
                                None if ln is None else ln.weight, None if ln is None else ln.bias,
                                _slope_of(act), fused_p, ops.next_seed() if fused_p > 0 else 0,
@@ -107,6 +109,11 @@ def encoder_branches(branches, x, cov=None):
     [+ extra_linear_rep], hidden_lib + its head).  Branches of the reference's default shape run together: their
     first-layer products as one launch over the packed weights (precision 'bf16') and their tails as ONE fused kernel
     (ops.enc_branches); everything else goes layer by layer."""
+    if isinstance(x, ops.BatchTiles) and ops.get_precision() == "bf16":
+        # the branches' first-layer weights become adjacent, 128-byte aligned row blocks of one tensor (idempotent)
+        firsts = [f[0].weight for f, _ in branches if isinstance(f, HipFCNN) and len(f) and isinstance(f[0], nn.Linear)]
+        if len(firsts) == len(branches) and all(w.is_cuda for w in firsts):
+            ops.home_first_layers(*firsts[:ops.ENC_MAX_BRANCHES])
     specs = [_branch_spec(f, fin, x, cov) for f, fin in branches]
     outs = [None] * len(branches)
     fusable = [i for i, sp in enumerate(specs) if sp is not None]
@@ -115,8 +122,6 @@ def encoder_branches(branches, x, cov=None):
         by_slope.setdefault(specs[i]["slope"], []).append(i)
     for slope, idx in by_slope.items():
         idx = idx[:ops.ENC_MAX_BRANCHES]
-        if len(idx) == 2 and ops.get_precision() == "bf16":
-            ops.pack_first_layers(specs[idx[0]]["W1"], specs[idx[1]]["W1"])
         res = ops.enc_branches(x, [specs[i] for i in idx], slope, cov=cov)
         for i, r in zip(idx, res):
             outs[i] = r

@@ -179,7 +179,7 @@ def test_two_branches_in_one_launch(prec, pack, B):
             devs.append({k: v.clone().to(DEV).requires_grad_(True) for k, v in P.items()})
         if pack:
             assert ops.pack_first_layers(devs[0]["W1"], devs[1]["W1"])
-            assert devs[1]["W1"].data_ptr() == devs[0]["W1"].data_ptr() + 4 * H1 * F
+            assert devs[1]["W1"].data_ptr() == devs[0]["W1"].data_ptr() + 4 * H1 * devs[0]["W1"].stride(0)
             assert torch.equal(devs[1]["W1"].detach().cpu(), refs[1][0]["W1"])
         tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), rows)
         outs = ops.enc_branches(tiles, devs, 0.01)
@@ -315,6 +315,70 @@ def test_covariate_columns_fused_adamw_matches_separate_step(C):
             for d in devs:
                 sh = ops.shadow_of(d["W1"], create=False)
                 assert sh is not None and torch.equal(sh[:, :F + C].float(), d["W1"].detach().bfloat16().float())
+        for a, b in zip(*res):
+            for k in a:
+                assert torch.allclose(a[k], b[k], rtol=2e-5, atol=2e-6), (k, float((a[k] - b[k]).abs().max()))
+    finally:
+        S.set_precision("fp32")
+
+
+@pytest.mark.parametrize("F,C", [(601, 0), (601, 3), (1001, 4), (640, 0)])
+def test_homed_first_layers_any_feature_count(F, C):
+    """ops.home_first_layers: the first-layer weights of an encoder's branches as row blocks of one tensor whose rows
+    start on 128-byte boundaries.  Feature counts that are no multiple of 4 / 32 (and covariate blocks behind them) keep
+    the fused weight-gradient + AdamW launch; two steps of it against the same steps through plain gradients + the
+    multi-tensor AdamW kernel (which addresses the padded rows through ld_p); shapes, values, state_dict and deepcopy are
+    those of ordinary parameters."""
+    import copy
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision("bf16")
+    try:
+        B, H1, H2 = 192, 132, 16
+        Ft = F + C
+        rng = np.random.default_rng(F + C)
+        m = _csr(rng, B, F, 0.1)
+        tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), np.arange(B))
+        x = torch.tensor(np.asarray(m.todense(), dtype=np.float32))
+        cov = torch.randn(B, C, generator=torch.Generator().manual_seed(3)) if C else None
+        covd = None if cov is None else cov.to(DEV)
+        res = []
+        for fuse in (False, True):
+            devs = []
+            for bi, N3 in enumerate((H2, 1)):
+                g, P, q, out_r = _draw(F, H1, H2, N3, x, lambda t: t.double(), 70 + bi, cov=cov)
+                devs.append({k: torch.nn.Parameter(v.clone().to(DEV)) for k, v in P.items()})
+            before = [d["W1"].detach().clone() for d in devs]
+            assert ops.home_first_layers(devs[0]["W1"], devs[1]["W1"])
+            ld = (Ft + 31) // 32 * 32
+            for d, w0 in zip(devs, before):
+                assert tuple(d["W1"].shape) == (H1, Ft) and d["W1"].stride() == (ld, 1) and d["W1"].data_ptr() % 128 == 0
+                assert torch.equal(d["W1"].detach(), w0)
+            assert devs[1]["W1"].data_ptr() == devs[0]["W1"].data_ptr() + 4 * H1 * ld
+            assert ops.home_first_layers(devs[0]["W1"], devs[1]["W1"])          # idempotent
+            opt = S.FusedAdamW([{"params": [p for d in devs for p in d.values()], "weight_decay": 1e-2, "lr": 1e-2}])
+            if fuse:
+                opt.fuse_first_layer(devs[0]["W1"], devs[1]["W1"])
+            for _ in range(2):
+                opt.zero_grad()
+                outs = ops.enc_branches(tiles, devs, 0.01, cov=covd)
+                sum((o * o).sum() for o in outs).backward()
+                if fuse:
+                    assert devs[0]["W1"].grad is None and devs[1]["W1"].grad is None, "the fused path must have taken the step"
+                opt.step()
+            for d in devs:
+                sh = ops.shadow_of(d["W1"], create=False)
+                assert sh is not None and torch.equal(sh[:, :Ft].float(), d["W1"].detach().bfloat16().float())
+                assert float(sh[:, Ft:].float().abs().max()) == 0.0 if sh.shape[1] > Ft else True
+                st = opt.state[d["W1"]]
+                assert st["exp_avg"].stride() == (ld, 1) and st["exp_avg_sq"].stride() == (ld, 1)
+            # an ordinary parameter to its users
+            sd = {k: v.detach().clone() for k, v in devs[0].items()}
+            cp = copy.deepcopy(devs[0]["W1"])
+            assert cp.is_contiguous() and torch.equal(cp.detach(), devs[0]["W1"].detach())
+            with torch.no_grad():
+                devs[0]["W1"].copy_(sd["W1"])
+            res.append([{k: v.detach().clone() for k, v in d.items()} for d in devs])
         for a, b in zip(*res):
             for k in a:
                 assert torch.allclose(a[k], b[k], rtol=2e-5, atol=2e-6), (k, float((a[k] - b[k]).abs().max()))

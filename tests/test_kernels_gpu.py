@@ -519,7 +519,7 @@ def test_bf16_shadow_tracks_weights(S):
         out = S.ops.fcnn_layer(tiles, None, W, b, None, None, 0.01)
         opt.zero_grad(); out.square().mean().backward(); opt.step()
         sh = S.ops.shadow_of(W, create=False)
-        assert sh is not None and sh.shape == (H, 336)
+        assert sh is not None and sh.shape == (H, 384)       # rows padded to 128 bytes
         assert torch.equal(sh[:, :F], W.detach().bfloat16()) and bool((sh[:, F:] == 0).all())
     with torch.no_grad():
         W.mul_(0.5)
