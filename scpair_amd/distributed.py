@@ -269,3 +269,106 @@ def feature_sharded_first_layer(W_block, x_cols, sync: GradSync, local_fwd, loca
     local_fwd(x_cols, W_block) -> [B_global, H];  local_dw(x_cols, dY_global, W_block.shape) -> [H, F_r]
     share   : this rank's n_r / n_total of the step's valid label elements (GradSync.share_of)"""
     return _FeatureShardedFn.apply(W_block, x_cols, sync, local_fwd, local_dw, share)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The feature-sharded first layer wired to the fused encoder path (ops.EncBranchesFn) and the trainers
+# ---------------------------------------------------------------------------------------------------------
+class _StepShard:
+    """What ops.EncBranchesFn reads off a minibatch's tile list (`tiles.shard`) in feature-sharded training."""
+
+    def __init__(self, sync, width, n_local, share):
+        self.sync, self.rank, self.world = sync, sync.rank, sync.world
+        self.width, self.n_local, self.share = int(width), int(n_local), share
+
+
+class FirstLayerShard:
+    """Feature-sharded data parallelism for the wide first layer of an encoder.
+
+    Every rank owns the column block W[:, lo:hi) of the encoder's first-layer weight(s) with its AdamW state, and holds
+    the columns [lo, hi) of ALL cells of a split (DeviceCSR.col_block) instead of all columns of its own cells.  Per step:
+      forward  : the rank multiplies the GLOBAL batch's columns with its block; ONE all-reduce of the pre-activations
+                 (B_global x H floats) replaces the all-reduce of the dense weight gradient (H x F);
+      backward : the ranks' dY rows (weighted by their share of the step's label elements) are all-gathered; the
+                 block's gradient over the global batch is then complete on its rank, so its AdamW step can run inside the
+                 weight-gradient kernel again (K2'), on 1 / world of the optimiser state and traffic.
+    Everything behind the first layer stays cell-sharded data parallel (GradSync.exchange of the small tensors)."""
+
+    def __init__(self, sync: GradSync, n_features: int):
+        self.sync, self.rank, self.world = sync, sync.rank, sync.world
+        self.F = int(n_features)
+        align = 128 if self.F >= self.world * 1024 else 1      # whole feature tiles of the weight-gradient kernel
+        per = -(-self.F // self.world)
+        per = -(-per // align) * align
+        self.bounds = [(min(self.F, r * per), min(self.F, (r + 1) * per)) for r in range(self.world)]
+        if any(hi <= lo for lo, hi in self.bounds):
+            raise ValueError(f"FirstLayerShard: {self.F} features cannot be split over {self.world} ranks")
+        self.lo, self.hi = self.bounds[self.rank]
+        self._sharded = []
+
+    # -- modules ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _first_linears(encoder, names):
+        out = []
+        for seq in (getattr(encoder, n_, None) for n_ in names):
+            while isinstance(seq, torch.nn.Sequential) and len(seq) > 0:
+                seq = seq[0]
+            if isinstance(seq, torch.nn.Linear):
+                out.append(seq)
+        return out
+
+    def shard_module(self, encoder, names=("hidden_rep", "hidden_lib", "enc_hidden", "enc_lib")):
+        """Replace the first-layer weights of `encoder` (already identical on every rank) by this rank's column block.
+        Call before the optimiser is built.  Returns the new parameters."""
+        new = []
+        for lin in self._first_linears(encoder, names):
+            if lin.weight.shape[1] != self.F:
+                raise ValueError("FirstLayerShard: the first layer takes covariates or another feature count")
+            with torch.no_grad():
+                blk = lin.weight.detach()[:, self.lo:self.hi].clone()
+            lin.weight = torch.nn.Parameter(blk)
+            lin.in_features = self.hi - self.lo
+            lin.weight._scp_feature_sharded = True
+            new.append(lin.weight)
+        return new
+
+    def unshard_module(self, encoder, names=("hidden_rep", "hidden_lib", "enc_hidden", "enc_lib")):
+        """The inverse: every rank gets the full first-layer weights back (all-gather of the blocks), e.g. on the
+        checkpoint copy that the trainer returns.  Idempotent."""
+        for lin in self._first_linears(encoder, names):
+            if lin.weight.shape[1] == self.F and not getattr(lin.weight, "_scp_feature_sharded", False):
+                continue
+            w = lin.weight.detach()
+            H = w.shape[0]
+            per = max(hi - lo for lo, hi in self.bounds)
+            mine = torch.zeros((H, per), dtype=w.dtype, device=w.device)
+            mine[:, :self.hi - self.lo] = w
+            parts = self.sync.gather_rows(mine.reshape(-1)).view(self.world, H, per)
+            full = torch.cat([parts[r, :, :hi - lo] for r, (lo, hi) in enumerate(self.bounds)], dim=1).contiguous()
+            lin.weight = torch.nn.Parameter(full, requires_grad=lin.weight.requires_grad)
+            lin.in_features = self.F
+        return encoder
+
+    # -- data ------------------------------------------------------------------------------------------------
+    def col_csr(self, csr):
+        """This rank's column block of a split (all cells), with the padding row the batches' slices are padded with."""
+        return csr.col_block(self.lo, self.hi, pad_row=True)
+
+    def batch_tiles(self, col_csr, rows_global, share=None):
+        """Tile list of a GLOBAL batch (row ids into the split; every rank passes the same ids) over this rank's columns.
+        The ranks' slices (GradSync.shard's rule) are padded to a common multiple of 64 rows with the empty padding row, so
+        cell blocks never straddle ranks.  share: this rank's n_r / n_total of the step's label elements (device scalar;
+        None for forward-only use).  Returns (tiles, this rank's row ids)."""
+        from .sparse import BatchTiles
+        rows_global = np.asarray(rows_global, dtype=np.int64)
+        parts = np.array_split(rows_global, self.world)
+        if min(len(p) for p in parts) == 0:
+            raise ValueError("feature-sharded first layer: every rank needs at least one row of each global batch")
+        width = (max(len(p) for p in parts) + 63) // 64 * 64
+        pad_id = col_csr.n_rows - 1
+        padded = np.full(self.world * width, pad_id, dtype=np.int64)
+        for r, p in enumerate(parts):
+            padded[r * width:r * width + len(p)] = p
+        t = BatchTiles(col_csr, padded, want_lib=False)
+        t.shard = _StepShard(self.sync, width, len(parts[self.rank]), share)
+        return t, parts[self.rank]

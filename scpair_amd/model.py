@@ -426,7 +426,8 @@ class scPair_object():
                  memory_efficient_loading=True,
                  val_chunk=4096,
                  verbose=True,
-                 grad_sync=None, fuse_optimizer=True, input_transform=None, capture_step=False):
+                 grad_sync=None, fuse_optimizer=True, input_transform=None, capture_step=False,
+                 shard_first_layer=False):
         self.scobj = scobj
         self.modalities = modalities
         self.modality_names = list(modalities.keys())
@@ -476,6 +477,10 @@ class scPair_object():
         self.val_chunk = int(val_chunk)
         self.verbose = verbose
         self.grad_sync = grad_sync          # data-parallel hook (scpair_amd.distributed.GradSync) or None
+        # data parallel only: every rank owns a COLUMN block of the wide first-layer weights and their AdamW state
+        # (distributed.FirstLayerShard) instead of a replica whose dense gradient is all-reduced every step.  Needs the
+        # fused encoder shape (no covariates, no BatchNorm) and global batches of at least `world` rows.
+        self.shard_first_layer = bool(shard_first_layer) and grad_sync is not None
         self.fuse_optimizer = fuse_optimizer  # AdamW step of the first-layer weights inside their dW kernel (1 process)
         # opt-in, single process: full-size minibatch steps are recorded once per direction as a HIP graph and
         # replayed (scpair_amd.graph.CapturedStep; same kernels in the same order, so results do not change)
@@ -635,17 +640,32 @@ class scPair_object():
         return rep
 
     @torch.no_grad()
-    def _eval_split(self, encoder, decoder, xcsr, ycsr, cov, use_lib, likelihood):
+    def _eval_split(self, encoder, decoder, xcsr, ycsr, cov, use_lib, likelihood, shard=None):
         """Full-split validation loss = sum(chunk_loss * chunk_count) / sum(count): identical to the reference's
-        single full-split mean (model.py:777)."""
+        single full-split mean (model.py:777).  shard (feature-sharded first layer): xcsr is this rank's column block of
+        the split; every chunk is a global batch whose rows the ranks divide among themselves."""
         evaluating_mode(encoder, decoder)
-        n = xcsr.n_rows
+        n = ycsr.n_rows
         num = torch.zeros((), dtype=torch.float64, device=self.device)
         den = torch.zeros((), dtype=torch.float64, device=self.device)
-        for ci, r0 in enumerate(range(0, n, self.val_chunk)):
-            if self.grad_sync is not None and ci % self.grad_sync.world != self.grad_sync.rank:
+        starts = list(range(0, n, self.val_chunk))
+        ends = starts[1:] + [n]
+        if shard is not None and len(starts) > 1 and ends[-1] - starts[-1] < shard.world:
+            starts.pop(); ends.pop(-2)            # a last chunk with fewer rows than ranks joins the one before it
+        for ci, (r0, r1) in enumerate(zip(starts, ends)):
+            if shard is None and self.grad_sync is not None and ci % self.grad_sync.world != self.grad_sync.rank:
                 continue                          # data parallel: every rank takes every world-th chunk
-            rows = np.arange(r0, min(n, r0 + self.val_chunk))
+            rows = np.arange(r0, r1)
+            if shard is not None:
+                tx, rows = shard.batch_tiles(xcsr, rows)
+                ty = BatchTiles(ycsr, rows, want_lib=True)
+                lib = ty.lib.reshape(-1, 1) if use_lib else None
+                loss = eval_net(tx, ty, lib, encoder, decoder, likelihood, add_cov=False, input_batch=None, output_batch=None)
+                cnt = float(len(rows) * ycsr.n_cols) - (ty.nnan.double()[0] if likelihood == "ber" else 0.0)
+                cnt = torch.as_tensor(cnt, dtype=torch.float64, device=self.device)
+                num += loss.double() * cnt
+                den += cnt
+                continue
             tx = BatchTiles(xcsr, rows, want_lib=False)
             ty = BatchTiles(ycsr, rows, want_lib=True)
             c = None if cov is None else cov[r0:r0 + len(rows)]
@@ -829,7 +849,8 @@ class scPair_object():
             if isinstance(seq, nn.Linear):
                 firsts.append(seq.weight)
         opt._dp_sink = None
-        if self.grad_sync is None:
+        if self.grad_sync is None or (firsts and all(getattr(p, "_scp_feature_sharded", False) for p in firsts)):
+            # single process, or feature-sharded data parallel (the block's gradient is complete on its rank)
             if self.fuse_optimizer:
                 opt.fuse_first_layer(*firsts)
         elif self.grad_sync.compress and ops.get_precision() == "bf16" and firsts and all(p.is_cuda for p in firsts):
@@ -844,7 +865,7 @@ class scPair_object():
             ops.set_bn_sync_weight(self.grad_sync.share_of(n_valid, self.device))
         if loss is not None:
             loss.backward()
-        params = [p for g in optimizer.param_groups for p in g['params']]
+        params = [p for g in optimizer.param_groups for p in g['params'] if not getattr(p, "_scp_feature_sharded", False)]
         gl = self.grad_sync.exchange(params, n_valid, loss, sink=getattr(optimizer, '_dp_sink', None),
                                      some_rank_empty=some_rank_empty)
         optimizer.step()
@@ -885,12 +906,20 @@ class scPair_object():
             n_cov = 0 if ctr is None else ctr.shape[1]
             dist = self.modalities[output_modality]
             encoder, decoder, use_lib = self._build_predictor(input_modality, output_modality, xtr.n_cols, ytr.n_cols, n_cov)
-            optimizer = self._make_optimizer(encoder, decoder)
-            scheduler = self.get_scheduler(optimizer)
+            shard = None
             if self.grad_sync is not None:
                 self._check_dp(encoder, decoder)
                 self.grad_sync.broadcast(list(encoder.parameters()) + list(decoder.parameters()) +
                                          list(encoder.buffers()) + list(decoder.buffers()))
+                if self.shard_first_layer:
+                    if n_cov or self.batchnorm or dist == 'gau':
+                        raise ValueError("shard_first_layer needs cov=None, batchnorm=False and a count / Bernoulli output")
+                    from .distributed import FirstLayerShard
+                    shard = FirstLayerShard(self.grad_sync, xtr.n_cols)
+                    shard.shard_module(encoder)
+                    xtr_cols, xva_cols = shard.col_csr(xtr), shard.col_csr(xva)
+            optimizer = self._make_optimizer(encoder, decoder)
+            scheduler = self.get_scheduler(optimizer)
             set_seed(self.SEED)
             loader = _index_loader(xtr.n_rows, self.batch_size) if batch_replay is None else None
             ytr_dense = ytr.to_dense().to(self.device) if dist == 'gau' else None
@@ -915,7 +944,11 @@ class scPair_object():
                 step_losses = []
                 for rows in batches:
                     empty_somewhere = False
-                    if self.grad_sync is not None:
+                    tx = None
+                    if shard is not None:
+                        # feature-sharded first layer: the encoder input is the GLOBAL batch over this rank's columns
+                        tx, rows = shard.batch_tiles(xtr_cols, rows)
+                    elif self.grad_sync is not None:
                         empty_somewhere = self.grad_sync.some_rank_empty(len(rows))
                         self._bn_step(empty_somewhere)
                         rows = self.grad_sync.shard(rows)
@@ -927,7 +960,8 @@ class scPair_object():
                     if stepper is not None and stepper.wants(rows):
                         step_losses.append(stepper.step(rows, rows_dev))
                         continue
-                    tx = BatchTiles(xtr, rows_dev, want_lib=False, rows_host=rows)
+                    if tx is None:
+                        tx = BatchTiles(xtr, rows_dev, want_lib=False, rows_host=rows)
                     c = None if ctr is None else ctr[rows_dev]
                     if dist == 'gau':
                         ty, lib = ytr_dense[rows_dev], None
@@ -937,7 +971,8 @@ class scPair_object():
                     loss = self._train_step(tx, ty, lib, encoder, decoder, optimizer, dist, c, empty_somewhere)
                     step_losses.append(loss)
                 hist["train_loss"].extend(step_losses)
-                val_total_loss = float(self._eval_split(encoder, decoder, xva, yva, cva, use_lib, dist).item())
+                val_total_loss = float(self._eval_split(encoder, decoder, xva if shard is None else xva_cols, yva, cva,
+                                                        use_lib, dist, shard=shard).item())
                 hist["val_loss"].append(val_total_loss)
                 if scheduler is not None and optimizer.param_groups[0]['lr'] > 1e-7:
                     scheduler.step()
@@ -957,6 +992,8 @@ class scPair_object():
             self.history[key] = hist
             encoder_dict[key] = copy.deepcopy(encoder_ckpt.eval())
             decoder_dict[key] = copy.deepcopy(decoder_ckpt.eval())
+            if shard is not None:                 # the returned encoder holds the full first-layer weights on every rank
+                shard.unshard_module(encoder_dict[key])
             if self.save_model is True:
                 if self.save_path is None:
                     self.save_path = os.getcwd()
@@ -976,6 +1013,9 @@ class scPair_object():
         # weight of this rank's mean in the global-batch mean = its share of the valid label elements
         n_valid = float(ty.shape[0] * ty.shape[1]) if not isinstance(ty, BatchTiles) or dist != "ber" else \
             (float(ty.B * ty.F) - ty.nnan.double()[0])
+        shd = getattr(tx, "shard", None)
+        if shd is not None:                       # read by the first layer's backward: weight of this rank's dY rows
+            shd.share = self.grad_sync.share_of(n_valid, self.device)
         return self._dp_step(loss, n_valid, optimizer, some_rank_empty)
 
     def train_bidirectional_mapping(self):

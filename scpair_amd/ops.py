@@ -645,7 +645,12 @@ class EncBranchesFn(torch.autograd.Function):
         L = _lib.lib()
         nb = len(cfg["br"])
         P = [tensors[10 * i:10 * i + 10] for i in range(nb)]
-        Bn, F = x.shape
+        Bg, F = x.shape                            # rows of the first-layer product
+        # feature-sharded data parallelism (distributed.FirstLayerShard): x holds the GLOBAL batch (every rank's slice padded
+        # to a common length) restricted to this rank's columns, W1 is this rank's column block; the ranks' partial products
+        # are summed and the encoder goes on with this rank's own rows
+        shd = getattr(x, "shard", None)
+        Bn = Bg if shd is None else shd.n_local    # rows the tail works on
         dev = P[0][0].device
         ns = _ns()
         H1s = [p_[0].shape[0] for p_ in P]
@@ -655,6 +660,9 @@ class EncBranchesFn(torch.autograd.Function):
         cov = None if cov is None else _f32c(cov)
         Cn = 0 if cov is None else cov.shape[1]
         Ft = F + Cn                                 # columns of the first-layer weights
+        if shd is not None and (Cn or Bn <= 0 or Bg != shd.world * shd.width):
+            raise ValueError("feature-sharded first layer: no covariate block, a non-empty slice on every rank and a batch "
+                             "of world x width rows are required")
         for p_ in P:
             if p_[0].shape[1] != Ft:
                 raise ValueError(f"encoder: first layer expects {p_[0].shape[1]} inputs, the minibatch has {F} features"
@@ -674,13 +682,13 @@ class EncBranchesFn(torch.autograd.Function):
         for g in groups:
             Hg = sum(H1s[i] for i in g)
             if use_bf:
-                tiles_ = ((Bn + 255) // 256) * ((Hg + 127) // 128)
+                tiles_ = ((Bg + 255) // 256) * ((Hg + 127) // 128)
                 nsp = max(1, min(_cfg.get("fwd_wgs", 512) // max(tiles_, 1), ((F + 63) // 64) // 4, 16), L.scp_spmm_fwd_bf16_min_split(F))
             else:
-                nsp = _pick_split(Bn, Hg, F)
+                nsp = _pick_split(Bg, Hg, F)
             nsp = L.scp_gemm_split_count(F, nsp)
             nsplits.append(nsp)
-            slab_sizes.append(nsp * Bn * Hg)
+            slab_sizes.append(nsp * Bg * Hg)
         sizes = list(slab_sizes) + [Bn * n for n in nouts]
         if train:
             for i in range(nb):
@@ -691,21 +699,33 @@ class EncBranchesFn(torch.autograd.Function):
         saves = [pieces[len(groups) + nb + 4 * i:len(groups) + nb + 4 * i + 4] if train else (None,) * 4 for i in range(nb)]
         stream = _lib.stream()
         slab_of = {}
+        shd_keep = []
         for gi, g in enumerate(groups):
             Hg = sum(H1s[i] for i in g)
             W1 = P[g[0]][0]
             if use_bf:
                 sh = shadows[g[0]]
-                _lib.check(L.scp_spmm_fwd_bf16(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), _lib.ptr(x.pk),
+                _lib.check(L.scp_spmm_fwd_bf16(Bg, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), _lib.ptr(x.pk),
                                                sh.data_ptr(),
                                                sh.shape[1], slabs[gi].data_ptr(), Hg, nsplits[gi], stream),
                            "scp_spmm_fwd_bf16")
             else:
-                _lib.check(L.scp_spmm_fwd(Bn, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(),
+                _lib.check(L.scp_spmm_fwd(Bg, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(),
                                           ldws[g[0]], slabs[gi].data_ptr(), Hg, None, nsplits[gi], ns, stream), "scp_spmm_fwd")
+            base, stride_, nsl = slabs[gi].data_ptr(), Bg * Hg, nsplits[gi]
+            if shd is not None:
+                # this rank's partial product of the global batch -> summed over the ranks; the tail reads its own rows
+                if nsl > 1:
+                    y = torch.empty((Bg, Hg), dtype=torch.float32, device=dev)
+                    slab_reduce(slabs[gi], nsl, Bg, Hg, y)
+                else:
+                    y = slabs[gi][:Bg * Hg].view(Bg, Hg)
+                shd.sync._sum(y)
+                shd_keep.append(y)
+                base, stride_, nsl = y.data_ptr() + 4 * shd.rank * shd.width * Hg, 0, 1
             col = 0
             for i in g:
-                slab_of[i] = (slabs[gi].data_ptr() + 4 * col, Bn * Hg, Hg, nsplits[gi])
+                slab_of[i] = (base + 4 * col, stride_, Hg, nsl)
                 col += H1s[i]
         any_drop = any(b_["p1"] > 0 or b_["p2"] > 0 for b_ in cfg["br"])
         seed_dev = _seed_dev() if any_drop else None
@@ -734,6 +754,7 @@ class EncBranchesFn(torch.autograd.Function):
             ctx.save_for_backward(*[t for t in tensors if t is not None])
             ctx.present = [t is not None for t in tensors]
             ctx.dims = (Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn, ldws)
+            ctx.shd = shd
         return tuple(outs)
 
     @staticmethod
@@ -748,7 +769,9 @@ class EncBranchesFn(torch.autograd.Function):
         cfg, arr, t = ctx.cfg, ctx.arr, ctx.tiles
         dev = P[0][0].device
         stream = _lib.stream()
-        ldt = (Bn + 63) // 64 * 64
+        shd = ctx.shd
+        Bg = Bn if shd is None else shd.world * shd.width      # rows of the first-layer weight-gradient product
+        ldt = (Bn + 63) // 64 * 64 if shd is None else shd.width
         # one allocation for every small gradient and the workspaces; the first-layer gradient operand separately
         sizes = []
         for i in range(nb):
@@ -761,7 +784,7 @@ class EncBranchesFn(torch.autograd.Function):
         if use_bf:
             for g in groups:
                 Hg = sum(H1s[i] for i in g)
-                tbuf = torch.empty((Hg, ldt), dtype=torch.bfloat16, device=dev)
+                tbuf = (torch.empty if shd is None else torch.zeros)((Hg, ldt), dtype=torch.bfloat16, device=dev)
                 row = 0
                 for i in g:
                     dYT[i] = (tbuf, row)
@@ -817,6 +840,9 @@ class EncBranchesFn(torch.autograd.Function):
             keep.append(do)
             m = arr[i]
             m.dOut, m.lddo = do.data_ptr(), do.shape[1]
+            if shd is not None and not use_bf:     # rows padded to the common slice length for the all-gather
+                dY1 = torch.zeros((shd.width, H1s[i]), dtype=torch.float32, device=dev)
+                keep.append(dY1)
             m.dY1, m.ldy = (None, 0) if use_bf else (dY1.data_ptr(), H1s[i])
             if use_bf:
                 tbuf, row = dYT[i]
@@ -855,14 +881,38 @@ class EncBranchesFn(torch.autograd.Function):
                         raise RuntimeError("encoder with a covariate block: the bf16 gradient sink is not supported")
                     row_ += H1s[i]
         _lib.check(L.scp_enc_tail_bwd(arr, nb, stream), "scp_enc_tail_bwd")
+        dy1_of = {}
+        if shd is not None:
+            # feature-sharded: every rank's rows of dY, weighted by its share of the step's label elements, are gathered;
+            # the gradient of this rank's column block over the GLOBAL batch is then complete here (no gradient exchange)
+            if use_bf:
+                for g in groups:
+                    tbuf = dYT[g[0]][0]
+                    if shd.share is not None:
+                        tbuf.mul_(shd.share.to(tbuf.dtype))
+                    Hg_ = tbuf.shape[0]
+                    full = shd.sync.gather_rows(tbuf.view(-1)).view(shd.world, Hg_, ldt).permute(1, 0, 2).reshape(Hg_, Bg)
+                    row = 0
+                    for i in g:
+                        dYT[i] = (full, row)
+                        row += H1s[i]
+                ldt = Bg
+            else:
+                for i in range(nb):
+                    d_ = keep[2 * i + 1]
+                    if shd.share is not None:
+                        d_.mul_(shd.share)
+                    dy1_of[i] = shd.sync.gather_rows(d_.view(-1)).view(Bg, H1s[i])
         # ---- first-layer weight gradient (and, where registered, the AdamW step in its epilogue) -------------------
         tp, tk, tv, tpk = _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), _lib.ptr(t.pk)
+        Bn = Bg
         for u, mode, payload in plan:
             Hu = sum(H1s[i] for i in u)
             W1 = P[u[0]][0]
             if mode == "plain32":
                 i = u[0]
-                _lib.check(L.scp_spmm_dw(Bn, H1s[i], F, tp, tk, tv, arr[i].dY1, H1s[i], payload.data_ptr(), Ft, ns, stream),
+                dy1_ptr = dy1_of[i].data_ptr() if shd is not None else arr[i].dY1
+                _lib.check(L.scp_spmm_dw(Bn, H1s[i], F, tp, tk, tv, dy1_ptr, H1s[i], payload.data_ptr(), Ft, ns, stream),
                            "scp_spmm_dw")
                 grads[i][0] = payload
                 continue
@@ -894,7 +944,7 @@ class EncBranchesFn(torch.autograd.Function):
                 for i in u:
                     grads[i][0] = payload[row_:row_ + H1s[i]]
                     row_ += H1s[i]
-        ctx.buf = ctx.tiles = ctx.arr = ctx.cov = None
+        ctx.buf = ctx.tiles = ctx.arr = ctx.cov = ctx.shd = None
         flat = [None, None]
         for i in range(nb):
             flat += grads[i]

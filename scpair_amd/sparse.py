@@ -95,6 +95,55 @@ class DeviceCSR:
         v.transform = (mode, float(scale) if mode == "log1p_norm" else 1.0)
         return v
 
+    def col_block(self, lo: int, hi: int, pad_row: bool = False):
+        """Columns [lo, hi) of every row as a new DeviceCSR (column ids re-based to 0), built on the device.  The
+        column-sharded view of a split that a rank holds when it owns the first-layer weights W[:, lo:hi) (feature-sharded
+        data parallelism).  pad_row: one empty row is appended (its id, .n_rows - 1, pads per-rank slices of a global
+        batch to a common length)."""
+        lo, hi = int(lo), int(hi)
+        if not 0 <= lo < hi <= self.shape[1]:
+            raise ValueError("col_block: need 0 <= lo < hi <= n_cols")
+        n = self.shape[0]
+        if self.nnz:
+            idx = self.indices[:self.nnz]
+            keep = (idx >= lo) & (idx < hi)
+            counts = torch.diff(self.indptr)
+            row_of = torch.repeat_interleave(torch.arange(n, device=self.device), counts)
+            new_counts = torch.bincount(row_of[keep], minlength=n)
+            indices = (idx[keep] - lo).to(torch.int32)
+            values = None if self.values is None else self.values[:self.nnz][keep]
+            del row_of, keep
+        else:
+            new_counts = torch.zeros(n, dtype=torch.int64, device=self.device)
+            indices = torch.zeros(0, dtype=torch.int32, device=self.device)
+            values = None if self.values is None else torch.zeros(0, dtype=torch.float32, device=self.device)
+        indptr = torch.zeros(n + 1 + (1 if pad_row else 0), dtype=torch.int64, device=self.device)
+        indptr[1:n + 1] = torch.cumsum(new_counts, 0)
+        if pad_row:
+            indptr[n + 1] = indptr[n]
+        out = DeviceCSR.from_device(indptr, indices, values, (n + (1 if pad_row else 0), hi - lo))
+        out.transform = self.transform
+        return out
+
+    @classmethod
+    def vstack(cls, parts):
+        """Rows of `parts` (same column count, same device, all with or all without values) stacked into one DeviceCSR."""
+        parts = list(parts)
+        if len(parts) == 1:
+            return parts[0]
+        ncol = parts[0].shape[1]
+        if any(p.shape[1] != ncol or (p.values is None) != (parts[0].values is None) for p in parts):
+            raise ValueError("vstack: parts differ in columns or in having values")
+        ips, off = [parts[0].indptr], int(parts[0].indptr_host[-1])
+        for p in parts[1:]:
+            ips.append(p.indptr[1:] + off)
+            off += int(p.indptr_host[-1])
+        indices = torch.cat([p.indices[:p.nnz] for p in parts])
+        values = None if parts[0].values is None else torch.cat([p.values[:p.nnz] for p in parts])
+        out = cls.from_device(torch.cat(ips), indices, values, (sum(p.shape[0] for p in parts), ncol))
+        out.transform = parts[0].transform
+        return out
+
     @property
     def n_rows(self):
         return self.shape[0]

@@ -125,6 +125,12 @@ def encoder_branches(branches, x, cov=None):
         res = ops.enc_branches(x, [specs[i] for i in idx], slope, cov=cov)
         for i, r in zip(idx, res):
             outs[i] = r
+    if getattr(x, "shard", None) is not None and any(o is None for o in outs):
+        # the collectives of the feature-sharded first layer live in the fused path only: fail loudly rather than run a
+        # branch on this rank's column block as if it were the whole input
+        raise RuntimeError("feature-sharded first layer: the encoder must have the fused shape (sparse minibatch, no "
+                           "covariate block, two FCNN layers with LayerNorm and no BatchNorm, widths H1 % 4 == 0, H1 <= 1024, "
+                           "H2 <= 64)")
     for i, (f, fin) in enumerate(branches):
         if outs[i] is None:
             h = f(x, cov)

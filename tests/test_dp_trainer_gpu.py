@@ -20,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _train(grad_sync, batch, epochs, with_mapping, precision="fp32", batchnorm=False):
+def _train(grad_sync, batch, epochs, with_mapping, precision="fp32", batchnorm=False, shard=False):
     import scpair_amd as S
     from tests.test_trajectory_gpu import _dicts
     d = U.load("traj_nb_ber")
@@ -29,22 +29,33 @@ def _train(grad_sync, batch, epochs, with_mapping, precision="fp32", batchnorm=F
     obj = S.scPair_object(None, cov=None, modalities=c["modalities"], SEED=0, hidden_layer=c["hidden"], dropout_rate=0.0,
                           batchnorm=batchnorm, layernorm=True, batch_size=batch, max_epochs=epochs,
                           device=torch.device("cuda:0"), save_model=False, zero_inflated=c["zero_inflated"],
-                          verbose=False, grad_sync=grad_sync, use_mixed_precision=(precision == "bf16"))
-    obj.train_predicting_networks(tr, va, te)
+                          verbose=False, grad_sync=grad_sync, use_mixed_precision=(precision == "bf16"),
+                          shard_first_layer=shard)
+    enc, _ = obj.train_predicting_networks(tr, va, te)
     if with_mapping:
         obj.reference_embeddings()
         obj.train_bidirectional_mapping()
-    return {k: (list(map(float, v["train_loss"])), list(map(float, v["val_loss"]))) for k, v in obj.history.items()}
+    hist = {k: (list(map(float, v["train_loss"])), list(map(float, v["val_loss"]))) for k, v in obj.history.items()}
+    if shard:
+        # the returned encoders hold the full first-layer weights again (all-gather of the ranks' column blocks)
+        names = list(c["modalities"].keys())
+        dims = {names[0]: tr[names[0] + "_train_mtx"].shape[1], names[1]: tr[names[1] + "_train_mtx"].shape[1]}
+        for k, e in enc.items():
+            w = e.hidden_rep[0].weight
+            assert w.shape[1] == dims[k.split(" to ")[0]] and e.hidden_rep[0].in_features == w.shape[1], (k, tuple(w.shape))
+        hist["_w_sum"] = ([float(enc[k].hidden_rep[0].weight.double().abs().sum()) for k in sorted(enc)], [])
+    return hist
 
 
-def _worker(rank, world, port, out, batch, epochs, with_mapping, precision="fp32", compress=False, batchnorm=False):
+def _worker(rank, world, port, out, batch, epochs, with_mapping, precision="fp32", compress=False, batchnorm=False,
+            shard=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=True)           # a stuck collective ends the rank with a traceback
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from scpair_amd.distributed import GradSync
-    hist = _train(GradSync(compress=compress), batch, epochs, with_mapping, precision, batchnorm)
+    hist = _train(GradSync(compress=compress), batch, epochs, with_mapping, precision, batchnorm, shard)
     faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         out.put(hist)
@@ -52,12 +63,13 @@ def _worker(rank, world, port, out, batch, epochs, with_mapping, precision="fp32
     dist.destroy_process_group()
 
 
-def _run_two_ranks(batch, epochs, with_mapping=False, precision="fp32", compress=False, batchnorm=False):
+def _run_two_ranks(batch, epochs, with_mapping=False, precision="fp32", compress=False, batchnorm=False, shard=False):
     world = 2
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out, batch, epochs, with_mapping, precision, compress, batchnorm))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, batch, epochs, with_mapping, precision, compress, batchnorm,
+                                                shard))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -210,3 +222,43 @@ def test_feature_sharded_first_layer_on_the_tile_list_kernels():
         ref_y, ref_g = Y.detach().numpy()[lo:hi], W.grad.numpy()[:, f0:f1]
         assert float(np.abs(y - ref_y).max()) < 1e-4 * float(np.abs(ref_y).max()), rank
         assert float(np.abs(gw - ref_g).max()) < 1e-4 * float(np.abs(ref_g).max()), rank
+
+
+def test_two_rank_trainer_with_feature_sharded_first_layer_reproduces_reference_trajectory():
+    """scPair_object(grad_sync=..., shard_first_layer=True): every rank owns a column block of the first-layer weights and
+    holds those columns of all cells; the all-reduce of the pre-activations and the all-gather of dY replace the all-reduce
+    of the dense first-layer gradient.  The two-rank run must follow the reference's single-process trajectory like the
+    replicated data-parallel run does (5e-4), ragged last batch (26 rows -> 13 + 13, padded to 64 per rank) included."""
+    hist = _run_two_ranks(U.cfg(U.load("traj_nb_ber"), "cfg")["batch"], 3, shard=True)
+    d = U.load("traj_nb_ber")
+    c = U.cfg(d, "cfg")
+    names = list(c["modalities"].keys())
+    steps_per_epoch = int(np.ceil(len(d["dir0/train_loss"]) / c["epochs"]))
+    for di in range(2):
+        tl, vl = hist[names[di] + " to " + names[1 - di]]
+        ref_t = d[f"dir{di}/train_loss"][: 3 * steps_per_epoch]
+        ref_v = d[f"dir{di}/val_loss"][:3]
+        assert len(tl) == len(ref_t) and len(vl) == 3
+        assert float(np.max(np.abs(np.array(tl) - ref_t) / np.abs(ref_t))) < 5e-4, di
+        assert float(np.max(np.abs(np.array(vl) - ref_v) / np.abs(ref_v))) < 5e-4, di
+
+
+def test_two_rank_feature_sharded_bf16_fused_step_matches_single_process():
+    """Precision 'bf16': each rank's block takes its AdamW step inside its weight-gradient kernel over the GLOBAL batch
+    (K2' per rank, no gradient exchange for the wide weights).  Losses and the magnitude of the reassembled first-layer
+    weights within the bf16 tolerance of the single-process bf16 run."""
+    h2 = _run_two_ranks(64, 2, precision="bf16", shard=True)
+    h1 = _train(None, 64, 2, False, precision="bf16")
+    w2 = h2.pop("_w_sum")[0]
+    _compare(h2, h1, 2e-2)
+    import scpair_amd as S
+    # single-process weights for the same two epochs
+    from tests.test_trajectory_gpu import _dicts
+    d = U.load("traj_nb_ber"); c = U.cfg(d, "cfg"); tr, va, te = _dicts(c, d)
+    obj = S.scPair_object(None, cov=None, modalities=c["modalities"], SEED=0, hidden_layer=c["hidden"], dropout_rate=0.0,
+                          batchnorm=False, layernorm=True, batch_size=64, max_epochs=2, device=torch.device("cuda:0"),
+                          save_model=False, zero_inflated=c["zero_inflated"], verbose=False, use_mixed_precision=True)
+    enc, _ = obj.train_predicting_networks(tr, va, te)
+    w1 = [float(enc[k].hidden_rep[0].weight.double().abs().sum()) for k in sorted(enc)]
+    for a, b in zip(w2, w1):
+        assert abs(a - b) < 2e-3 * abs(b), (w2, w1)
