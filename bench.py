@@ -70,6 +70,12 @@ def parse():
     ap.add_argument("--no-grad-sink", action="store_true",
                     help="N > 1, bf16 exchange: keep fp32 first-layer gradients + cast/copy instead of the bf16 exchange buffer")
     ap.add_argument("--zinb", action="store_true", help="same as --workload C3 on the C2 shapes")
+    ap.add_argument("--shard-first-layer", action="store_true",
+                    help="N > 1: feature-sharded first layers (every rank owns a column block of the wide weights and their "
+                         "AdamW state; reduce-scatter of pre-activations + all-gather of dY instead of the dense gradient "
+                         "all-reduce).  The default for N > 1 on the paired workloads without covariates / BatchNorm")
+    ap.add_argument("--replicated", action="store_true",
+                    help="N > 1: replicated first-layer weights and the dense gradient all-reduce (the round-2 scheme)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build each minibatch's tile lists at the start of its own step instead of during the previous one")
     ap.add_argument("--no-extras", action="store_true", help="skip the separately reported validation / mapping-stage rates")
@@ -156,8 +162,19 @@ class Direction:
         self.dist = out_dist
         self.fused = False
         self.sink = None
+        self.shard = None
         self.use_lib = sample_factor
         self.enc.train(); self.dec.train()
+
+    def apply_shard(self, S, shard, fuse):
+        """Feature-sharded data parallelism: the first-layer weights become this rank's column block (the optimiser is
+        rebuilt around the new parameters); their AdamW step runs in the weight-gradient kernel when `fuse`."""
+        self.first = shard.shard_module(self.enc)
+        self.opt = S.FusedAdamW(_groups(S, self.enc, self.dec))
+        self.shard = shard
+        if fuse:
+            self.opt.fuse_first_layer(*self.first)
+            self.fused = True
 
     def fuse(self):
         self.opt.fuse_first_layer(*self.first)
@@ -276,23 +293,54 @@ def main():
         models = [A, Bd]
     else:
         models = [VaeModel(S, a, a.genes, dev)]
+    # feature-sharded first layers: the scheme for N > 1 wherever it applies (paired workload, fused encoder shape, a global
+    # batch the weight-gradient kernel takes in one call); --replicated keeps the dense gradient all-reduce.  With one rank
+    # it only runs when asked for (SCPAIR_BENCH_FORCE_DIST=1 --shard-first-layer: the RCCL call sequence on a one-GPU box)
+    eligible = paired and not a.cov and not a.batchnorm and world * a.batch <= 32768 and a.precision == "bf16"
+    sharded = bool(use_dist and eligible and not a.replicated and (world > 1 or a.shard_first_layer))
+    if a.shard_first_layer and not sharded and use_dist:
+        raise SystemExit("--shard-first-layer: paired bf16 workloads without covariates / BatchNorm, at most 32768 cells per "
+                         "global batch")
     sync = None
     if use_dist:
         from scpair_amd.distributed import GradSync
         sync = GradSync(compress=(a.precision == "bf16" and not a.fp32_exchange))
         for d_ in models:
             sync.broadcast([p for m in d_.modules() for p in m.parameters()])
-            if sync.compress and not a.no_grad_sink and not a.cov:
+            if sync.compress and not a.no_grad_sink and not a.cov and not sharded:
                 d_.sink = sync.make_sink(d_.first)     # dW of the wide first layers goes straight to the bf16 exchange buffer
 
     fuse = (sync is None) and (not a.no_fuse_opt) and a.precision == "bf16"
     if fuse:
         for d_ in models:
             d_.fuse()
+    rna_cols = atac_cols = None
+    if sharded:
+        from scpair_amd.distributed import FirstLayerShard
+        for d_, nfeat in ((A, a.genes), (Bd, a.peaks)):
+            d_.sink = None
+            d_.apply_shard(S, FirstLayerShard(sync, nfeat), fuse=(not a.no_fuse_opt) and a.precision == "bf16")
+        # every rank holds ITS columns of ALL ranks' cells (the same entries in total as all columns of its own cells)
+        def cols_of(make, own, shard, seed0, **kw):
+            parts = []
+            for r in range(world):
+                full = own if r == rank else make(cells_here, shard.F, dev, seed=seed0 + r, **kw)
+                parts.append(full.col_block(shard.lo, shard.hi))
+                del full
+            return S.DeviceCSR.vstack(parts).col_block(0, shard.hi - shard.lo, pad_row=True)
+        rna_cols = cols_of(synth.make_rna_device, rna, A.shard, 100, target_density=a.rna_density)
+        atac_cols = cols_of(synth.make_atac_device, atac, Bd.shard, 200, p=a.p_atac)
+        torch.cuda.empty_cache()
 
     rng = np.random.default_rng(1234 + rank)
     state = {"perm": rng.permutation(cells_here), "cur": 0}
     state["perm_dev"] = torch.from_numpy(state["perm"]).to(dev)
+    # feature-sharded: a rank also needs the other ranks' row ids of every global batch; their generators are replayed here
+    peers = [{"rng": np.random.default_rng(1234 + r), "perm": None, "cur": 0} for r in range(world)] if sharded else []
+    for r_, pr in enumerate(peers):
+        pr["perm"] = pr["rng"].permutation(cells_here)
+        pr["perm_dev"] = torch.from_numpy(pr["perm"] + r_ * cells_here).to(dev)
+    share_dev = torch.full((), 1.0 / world, dtype=torch.float32, device=dev) if sharded else None
     adam_ev, fused_ev, exch_ev = [], [], []
 
     host_t = {"tiles": 0.0, "fwd": 0.0, "bwd": 0.0, "opt": 0.0}      # host enqueue time by phase (diagnostic)
@@ -354,6 +402,9 @@ def main():
         return rows, rows_dev
 
     def run_models(t_rna, t_atac, cov, time_it, side, prefetch=None):
+        x_rna, x_atac = t_rna, t_atac             # encoder inputs = the label tile lists, unless feature-sharded
+        if sharded:
+            (t_rna, x_rna), (t_atac, x_atac) = t_rna, t_atac
         if not paired:
             D = models[0]
             out = one_direction(D, t_rna, t_rna, cov, time_it)
@@ -362,14 +413,14 @@ def main():
                 prefetch()
             return (out,)
         if side is None:
-            la = one_direction(A, t_rna, t_atac, cov, time_it)
+            la = one_direction(A, x_rna, t_atac, cov, time_it)
             finish_direction(A, time_it)
-            lb = one_direction(Bd, t_atac, t_rna, cov, time_it)
+            lb = one_direction(Bd, x_atac, t_rna, cov, time_it)
             finish_direction(Bd, time_it)
             return la, lb
         # the two predictors share nothing but the minibatch: one stream each, both after the tile-list build
         cur = torch.cuda.current_stream()
-        for t in (t_rna, t_atac):
+        for t in ((t_rna, t_atac, x_rna, x_atac) if sharded else (t_rna, t_atac)):
             for x in (t.ptr, t.key, t.val, t.pk, t.lib, t.nnan, t.rows):
                 if x is not None:
                     for st in side:
@@ -378,7 +429,7 @@ def main():
             for st in side:
                 cov.record_stream(st)
         out = []
-        for st, (D, tx, ty) in zip(side, ((A, t_rna, t_atac), (Bd, t_atac, t_rna))):
+        for st, (D, tx, ty) in zip(side, ((A, x_rna, t_atac), (Bd, x_atac, t_rna))):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 out.append(one_direction(D, tx, ty, cov, time_it))
@@ -389,12 +440,30 @@ def main():
             cur.wait_stream(st)
         return out[0], out[1]
 
+    def global_rows():
+        out, out_dev = [], []
+        for r, pr in enumerate(peers):
+            if pr["cur"] + a.batch > cells_here:
+                pr["perm"], pr["cur"] = pr["rng"].permutation(cells_here), 0
+                pr["perm_dev"] = torch.from_numpy(pr["perm"] + r * cells_here).to(dev)        # one upload per epoch
+            out.append(pr["perm"][pr["cur"]:pr["cur"] + a.batch] + r * cells_here)
+            out_dev.append(pr["perm_dev"][pr["cur"]:pr["cur"] + a.batch])
+            pr["cur"] += a.batch
+        return np.concatenate(out), (torch.cat(out_dev) if len(out_dev) > 1 else out_dev[0].contiguous())
+
     def build_tiles():
         rows, rows_dev = next_rows()
         t0_ = pc()
         t_rna = S.BatchTiles(rna, rows_dev, want_lib=True, rows_host=rows)
         t_atac = S.BatchTiles(atac, rows_dev, want_lib=False, rows_host=rows) if paired else None
         cov = None if cov_all is None else cov_all[rows_dev]
+        if sharded:
+            # encoder inputs: the GLOBAL batch over this rank's columns; t_rna / t_atac stay the labels of its own rows
+            rg, rg_dev = global_rows()
+            x_rna, _ = A.shard.batch_tiles(rna_cols, rg, share_dev, rows_dev=rg_dev)
+            x_atac, _ = Bd.shard.batch_tiles(atac_cols, rg, share_dev, rows_dev=rg_dev)
+            host_t["tiles"] += pc() - t0_
+            return (t_rna, x_rna), (t_atac, x_atac), cov
         host_t["tiles"] += pc() - t0_
         return t_rna, t_atac, cov
 
@@ -463,7 +532,7 @@ def main():
     # HIP events around every launch of the candidate dominant kernels on that stream, so the durations hold no time
     # queued behind the other direction's kernels and agree with rocprofv3's per-kernel durations of this command ----
     state.pop("next_tiles", None)
-    if fuse:
+    if fuse or (sharded and A.fused):
         S.ops.set_fused_timer(fused_ev)
     n_roof = max(a.roofline_steps, 1)
     for _ in range(n_roof):
@@ -540,6 +609,15 @@ def main():
     if a.cov or a.batchnorm:
         wl += f", covariate levels {a.cov}, batchnorm {a.batchnorm}"
     any_sink = any(d_.sink is not None for d_ in models)
+    fs_info = None
+    if sharded:
+        Bg = world * a.batch
+        h_a, h_b = sum(p.shape[0] for p in A.first), sum(p.shape[0] for p in Bd.first)
+        fs_info = {"what": "feature-sharded first layers: per step and rank, SUM reduce-scatter of the pre-activations [B_global x H] "
+                           "fp32 forward and all-gather of dY^T [H x B_global] bf16 backward, per encoder",
+                   "allreduce_bytes_per_step": 4 * Bg * (h_a + h_b), "allgather_bytes_per_step": 2 * Bg * (h_a + h_b),
+                   "replaces_dense_gradient_allreduce_bytes": 2 * (a.genes * h_a + a.peaks * h_b),
+                   "first_layer_params_per_rank": sum(p.numel() for p in A.first + Bd.first)}
     out = {
         "metric": "training cells/sec (whole node) paired RNA+ATAC" if paired else "training cells/sec (whole node) unimodal RNA VAE",
         "value": a.batch * world * a.steps / dt,
@@ -553,11 +631,14 @@ def main():
                    "cells_resident_per_gpu": cells_here, "nnz_per_cell_rna": round(nnz_r, 1),
                    "nnz_per_cell_atac": round(nnz_a, 1), "precision": a.precision, "parallelism": f"dp{world}",
                    "streams": a.streams if paired else 1,
+                   "first_layer": ("feature-sharded" if sharded else "replicated"), "first_layer_exchange": fs_info,
                    "grad_exchange": ("none" if sync is None else (("bf16 wide (written by the dW kernel) + fp32 rest" if any_sink
                                                                     else "bf16 wide + fp32 rest") if sync.compress else "fp32")),
                    "backend": (backend if use_dist else None),
                    "optimizer": ("AdamW; wide weights (first layers" + (", G x G layer" if a.zinb else "") + ") updated in their "
-                                 "weight-gradient kernels") if fuse else "AdamW, one multi-tensor kernel",
+                                 "weight-gradient kernels") if fuse else
+                                ("AdamW; each rank's first-layer column block updated in its weight-gradient kernel, the rest in one "
+                                 "multi-tensor kernel" if (sharded and A.fused) else "AdamW, one multi-tensor kernel"),
                    "host_enqueue_ms_per_step": round(1e3 * t_issue / 10, 3),
                    "host_loop_ms_per_step": round(1e3 * t_host / a.steps, 3),
                    "host_enqueue_ms_by_phase": host_by_phase,

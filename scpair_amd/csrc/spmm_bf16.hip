@@ -17,7 +17,9 @@
 #include "scpair_hip.h"
 
 #define LDK 72
-#define PCH 255 // K-steps whose entry offsets are staged in LDS at a time
+#define PCH 255 // forward: K-steps whose entry offsets are staged in LDS at a time
+#define PCW 511 // weight gradient: cell blocks per call (entry ranges of a feature tile in every cell block, staged in LDS):
+                // 32 768 cells, the global batch of 8 ranks x 4096 under feature-sharded data parallelism
 
 struct SpArgs {
   int ncells, N, F;          // cells, hidden width, features
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* Bs = (__bf16*)smem_raw;        // [3][256][LDK]   X tile    [feature][cell]
   __bf16* As = Bs + 3 * BSZ;             // [2][128][LDK]   dYT tile  [hidden][cell]
-  int* ptrs = (int*)(As + 2 * ASZ);      // [2][PCH + 1]: entry range [start, end) of this feature tile per cell block
+  int* ptrs = (int*)(As + 2 * ASZ);      // [2][PCW + 1]: entry range [start, end) of this feature tile per cell block
   __shared__ int ovf[3];                 // step+1 of a step whose X buffer holds entries beyond the per-thread slots
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, hq = lane >> 5;
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
       ar[i] = *(const u32x4*)(g.D + (long)m * g.ldd + k);
     }
     q0 = ptrs[step];
-    q1 = ptrs[(PCH + 1) + step];
+    q1 = ptrs[(PCW + 1) + step];
     const int elast = max(q1 - 1, 0);
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
@@ -433,9 +435,9 @@ __global__ __launch_bounds__(512) void spmm_dw_bf16_kernel(SpArgs g) {
     }
   };
 
-  // entry ranges of this feature tile in every cell block (ncb <= PCH + 1, checked by the host)
-  for (int i = tid; i < 2 * (PCH + 1); i += 512) {
-    int which = i / (PCH + 1), cbx = i % (PCH + 1);
+  // entry ranges of this feature tile in every cell block (ncb <= PCW + 1, checked by the host)
+  for (int i = tid; i < 2 * (PCW + 1); i += 512) {
+    int which = i / (PCW + 1), cbx = i % (PCW + 1);
     ptrs[i] = (cbx < g.ncb) ? g.ptr[(long)cbx * g.F + (which ? nend : n0)] : 0;
   }
   zero_B(0);
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* Bs = (__bf16*)smem_raw;        // [2][128][LDK]   X tile    [feature][cell]
   __bf16* As = Bs + 2 * BSZ;             // [2][128][LDK]   dYT tile  [hidden][cell]
-  int* ptrs = (int*)(As + 2 * ASZ);      // [2][PCH + 1]: entry range [start, end) of this feature tile per cell block
+  int* ptrs = (int*)(As + 2 * ASZ);      // [2][PCW + 1]: entry range [start, end) of this feature tile per cell block
   __shared__ int ovf[3];                 // step+1 of a step whose X buffer holds entries beyond the per-thread slots
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, hq = lane >> 5;
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       ar[i] = *(const u32x4*)(g.D + (long)m * g.ldd + k);
     }
     q0 = ptrs[step];
-    q1 = ptrs[(PCH + 1) + step];
+    q1 = ptrs[(PCW + 1) + step];
     const int elast = max(q1 - 1, 0);
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
@@ -720,9 +722,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     }
   };
 
-  // entry ranges of this feature tile in every cell block (ncb <= PCH + 1, checked by the host)
-  for (int i = tid; i < 2 * (PCH + 1); i += 256) {
-    int which = i / (PCH + 1), cbx = i % (PCH + 1);
+  // entry ranges of this feature tile in every cell block (ncb <= PCW + 1, checked by the host)
+  for (int i = tid; i < 2 * (PCW + 1); i += 256) {
+    int which = i / (PCW + 1), cbx = i % (PCW + 1);
     ptrs[i] = (cbx < g.ncb) ? g.ptr[(long)cbx * g.F + (which ? nend : n0)] : 0;
   }
   zero_B(0);
@@ -1011,10 +1013,10 @@ extern "C" int scp_spmm_dw_bf16(int ncells, int N, int F, const int32_t* t_ptr, 
   SCP_CHECK(!t_val || t_pk, SCP_ERR_ARG, "scp_spmm_dw_bf16: value-carrying tile lists need the packed entries (t_pk) scp_tiles_build writes");
   SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_dw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
-  SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16: more than %d cells per call unsupported",
-            64 * (PCH + 1));
+  SCP_CHECK((ncells + 63) / 64 <= PCW + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16: more than %d cells per call unsupported",
+            64 * (PCW + 1));
   static uint64_t done_v = 0, done_n = 0;
-  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
+  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCW + 1) * sizeof(int);
   int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true, false>, smem, &done_v)
                  : set_smem((const void*)spmm_dw_bf16_kernel<false, false>, smem, &done_n);
   if (rc) return rc;
@@ -1044,15 +1046,15 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
             "scp_spmm_dw_adamw_bf16: value-carrying tile lists need the packed entries (t_pk) scp_tiles_build writes");
   SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_dw_adamw_bf16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
-  SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: more than %d cells per call unsupported",
-            64 * (PCH + 1));
+  SCP_CHECK((ncells + 63) / 64 <= PCW + 1, SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: more than %d cells per call unsupported",
+            64 * (PCW + 1));
   SCP_CHECK(ldw % 4 == 0 && ldw >= F && ldw >= 4 && ld_bf16 % 4 == 0 && ld_bf16 >= F &&
                 (((uintptr_t)W | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) == 0 && ((uintptr_t)W_bf16 % 8) == 0,
             SCP_ERR_SHAPE, "scp_spmm_dw_adamw_bf16: needs leading dimensions %% 4 == 0 and 16-byte aligned W / moments");
   SCP_CHECK(bc_dev || (bias_corr1 > 0.f && bias_corr2 > 0.f), SCP_ERR_ARG,
             "scp_spmm_dw_adamw_bf16: bias corrections must be > 0");
   static uint64_t done_v = 0, done_n = 0;
-  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
+  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCW + 1) * sizeof(int);
   static_assert((size_t)128 * 260 * sizeof(float) <= (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16),
                 "gradient tile must fit in the operand buffers");
   int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true, true>, smem, &done_v)
@@ -1073,7 +1075,7 @@ extern "C" int scp_spmm_dw_adamw_bf16(int ncells, int N, int F, const int32_t* t
   if (dw_tile_features(t_val != nullptr) == 128) {
     // two workgroups of 128 x 128 tiles per CU: the AdamW epilogue of one overlaps the K loop of the other
     static uint64_t d128_v = 0, d128_n = 0;
-    const size_t smem128 = (size_t)(2 * 128 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
+    const size_t smem128 = (size_t)(2 * 128 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCW + 1) * sizeof(int);
     static_assert((size_t)128 * 132 * sizeof(float) <= (size_t)(2 * 128 + 2 * 128) * LDK * sizeof(__bf16),
                   "gradient tile must fit in the operand buffers");
     rc = t_val ? set_smem((const void*)spmm_dw128_bf16_kernel<true, true>, smem128, &d128_v)
@@ -1105,10 +1107,10 @@ extern "C" int scp_spmm_dw_bf16_g16(int ncells, int N, int F, const int32_t* t_p
   SCP_CHECK(!t_val || t_pk, SCP_ERR_ARG, "scp_spmm_dw_bf16_g16: value-carrying tile lists need the packed entries (t_pk) scp_tiles_build writes");
   SCP_CHECK(ldt % 8 == 0 && ldt >= ((ncells + 63) / 64) * 64 && ((uintptr_t)dYT % 16) == 0, SCP_ERR_ARG,
             "scp_spmm_dw_bf16_g16: dYT needs a 16-byte aligned base, ld %% 8 == 0 and ld >= cells rounded up to 64");
-  SCP_CHECK((ncells + 63) / 64 <= PCH + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16_g16: more than %d cells per call unsupported",
-            64 * (PCH + 1));
+  SCP_CHECK((ncells + 63) / 64 <= PCW + 1, SCP_ERR_SHAPE, "scp_spmm_dw_bf16_g16: more than %d cells per call unsupported",
+            64 * (PCW + 1));
   static uint64_t done_v = 0, done_n = 0;
-  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCH + 1) * sizeof(int);
+  size_t smem = (size_t)(3 * 256 + 2 * 128) * LDK * sizeof(__bf16) + 2 * (PCW + 1) * sizeof(int);
   int rc = t_val ? set_smem((const void*)spmm_dw_bf16_kernel<true, false, true>, smem, &done_v)
                  : set_smem((const void*)spmm_dw_bf16_kernel<false, false, true>, smem, &done_n);
   if (rc) return rc;

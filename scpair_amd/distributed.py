@@ -52,14 +52,30 @@ class GradSync:
         return t
 
     def gather_rows(self, t):
-        """All-gather of one small 1-D tensor per rank -> [world, n] in rank order (the same on every rank).  Same host
+        """All-gather of one 1-D tensor per rank -> [world, n] in rank order (the same on every rank).  Same host
         detour as _sum for backends other than nccl."""
         src = t.detach()
+        if self._backend == "nccl" and src.is_cuda:
+            out = torch.empty((self.world, src.numel()), dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(out, src.contiguous().view(-1), group=self.group)
+            return out
         if self._backend != "nccl" and src.is_cuda:
             src = src.cpu()
         parts = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(parts, src.contiguous(), group=self.group)
         return torch.stack(parts).to(t.device)
+
+    def reduce_scatter_rows(self, t):
+        """t: [world * w, n] partial sums, rank-major row blocks.  Returns the [w, n] block of this rank summed over the
+        ranks: a reduce-scatter on nccl (half the bytes of an all-reduce), an all-reduce + slice elsewhere (gloo has no
+        reduce-scatter; it is the rehearsal backend only)."""
+        w = t.shape[0] // self.world
+        if self._backend == "nccl":
+            out = torch.empty((w, t.shape[1]), dtype=t.dtype, device=t.device)
+            dist.reduce_scatter_tensor(out, t.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
+            return out
+        self._sum(t)
+        return t[self.rank * w:(self.rank + 1) * w]
 
     def share_of(self, n_valid, device):
         """This rank's share n_r / n_total of a step's valid label elements (one small SUM all-reduce): the weight its
@@ -354,13 +370,20 @@ class FirstLayerShard:
         """This rank's column block of a split (all cells), with the padding row the batches' slices are padded with."""
         return csr.col_block(self.lo, self.hi, pad_row=True)
 
-    def batch_tiles(self, col_csr, rows_global, share=None):
+    def batch_tiles(self, col_csr, rows_global, share=None, rows_dev=None):
         """Tile list of a GLOBAL batch (row ids into the split; every rank passes the same ids) over this rank's columns.
         The ranks' slices (GradSync.shard's rule) are padded to a common multiple of 64 rows with the empty padding row, so
         cell blocks never straddle ranks.  share: this rank's n_r / n_total of the step's label elements (device scalar;
-        None for forward-only use).  Returns (tiles, this rank's row ids)."""
+        None for forward-only use).  rows_dev: the same ids as an int64 device tensor (saves the upload when the slices
+        need no padding).  Returns (tiles, this rank's row ids)."""
         from .sparse import BatchTiles
         rows_global = np.asarray(rows_global, dtype=np.int64)
+        n = len(rows_global)
+        if rows_dev is not None and n % (64 * self.world) == 0:
+            w = n // self.world
+            t = BatchTiles(col_csr, rows_dev, want_lib=False, rows_host=rows_global)
+            t.shard = _StepShard(self.sync, w, w, share)
+            return t, rows_global[self.rank * w:(self.rank + 1) * w]
         parts = np.array_split(rows_global, self.world)
         if min(len(p) for p in parts) == 0:
             raise ValueError("feature-sharded first layer: every rank needs at least one row of each global batch")

@@ -720,9 +720,9 @@ class EncBranchesFn(torch.autograd.Function):
                     slab_reduce(slabs[gi], nsl, Bg, Hg, y)
                 else:
                     y = slabs[gi][:Bg * Hg].view(Bg, Hg)
-                shd.sync._sum(y)
+                y = shd.sync.reduce_scatter_rows(y)          # [width, Hg]: this rank's rows, summed over the ranks
                 shd_keep.append(y)
-                base, stride_, nsl = y.data_ptr() + 4 * shd.rank * shd.width * Hg, 0, 1
+                base, stride_, nsl = y.data_ptr(), 0, 1
             col = 0
             for i in g:
                 slab_of[i] = (base + 4 * col, stride_, Hg, nsl)
@@ -1734,7 +1734,8 @@ class FusedAdamW(torch.optim.Optimizer):
             for p in group["params"]:
                 fz = _fused.get(id(p)) if _fused else None
                 if fz is not None and fz.pending and fz.opt is self and fz.param is p:
-                    if grad_scale != 1.0:
+                    if grad_scale != 1.0 and not getattr(p, "_scp_feature_sharded", False):
+                        # (a feature-sharded block's gradient already carries the ranks' shares: nothing left to scale)
                         raise RuntimeError("FusedAdamW: grad_scale is not available for weights updated during backward()")
                     if p.grad is not None:
                         raise RuntimeError("FusedAdamW: a weight updated during backward() also received a gradient")
