@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 export TMPDIR=/tmp
-ARGS="--cpu-steps 0 --steps 6 --warmup 3 --roofline-steps 0 --streams 1"
+ARGS="--cpu-steps 0 --steps 12 --warmup 3 --roofline-steps 0 --streams 1 --no-extras $BENCH_EXTRA"
 (cd _old && timeout -k 10 150 rocprofv3 --kernel-trace -d $ROOT/gpurun_out/ab_old -o r -- python3 bench.py $ARGS > /dev/null 2>&1)
 timeout -k 10 150 rocprofv3 --kernel-trace -d $ROOT/gpurun_out/ab_new -o r -- python3 bench.py $ARGS > /dev/null 2>&1
 python3 - <<PY
@@ -19,6 +19,6 @@ def load(d):
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in r.items()}, {k: len(v) for k, v in r.items()}
 a, na = load("$ROOT/gpurun_out/ab_old"); b, nb = load("$ROOT/gpurun_out/ab_new")
 for k in sorted(set(a) | set(b), key=lambda k: -(b.get(k) or a.get(k))):
-    if (b.get(k) or a.get(k)) > 30: print("%-70s old %8.1f (%3d)  new %8.1f (%3d)" % (k[:70], a.get(k, 0), na.get(k, 0), b.get(k, 0), nb.get(k, 0)))
+    if (b.get(k) or a.get(k)) > 3 and "at::" not in k and "rocprim" not in k: print("%-70s old %8.1f (%3d)  new %8.1f (%3d)" % (k[:70], a.get(k, 0), na.get(k, 0), b.get(k, 0), nb.get(k, 0)))
 PY
 rm -rf $ROOT/gpurun_out/ab_old $ROOT/gpurun_out/ab_new

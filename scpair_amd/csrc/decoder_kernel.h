@@ -75,6 +75,21 @@ __device__ __forceinline__ void img_put(__bf16* img, int rows, int ld, int row, 
   for (int s = 0; s < NS; s++) img[(s * rows + row) * ld + col] = t[s];
 }
 
+// A-operand fragment (32 rows m0.., 16 k-values k0..) of an image stored k-major, img[k][LDZ] with m contiguous: the
+// transposing LDS read hands lane i of a 16-lane group column i of a 4 (k) x 16 (m) block (lane 4q+p addresses row q,
+// columns 4p..4p+3), so dZ^T -- written once, as the weight gradient's operand -- also serves the dh product.
+// EXEC must be all ones (callers branch wave-uniformly).
+typedef __attribute__((ext_vector_type(4))) short dec_short4;
+__device__ __forceinline__ bf16x8 dec_read_tr(const __bf16* img, int k0, int m0, int lane) {
+  const int g = lane >> 5, mb = ((lane >> 4) & 1) * 16, q = (lane & 15) >> 2, p = lane & 3;
+  typedef __attribute__((address_space(3))) dec_short4 lds_s4;
+  const __bf16* a = img + (k0 + 8 * g + q) * LDZ + m0 + mb + 4 * p;
+  union { dec_short4 h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)a);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(a + 4 * LDZ));
+  return u.v;
+}
+
 template <int NS, int KP, int NPT, int MODE, bool VEC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dec_kernel(DecArgs g) {
   constexpr bool IS_BER = (MODE == MODE_BER_TRAIN || MODE == MODE_BER_EVAL);
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   __bf16* WB = hA + NS * CB * LDK_;               // [NS][64][LDK_]   B of Z
   __bf16* hT = WB + NS * FT * LDK_;               // [NS][KP][LDZ]    B of dW   ([k][cell])
   __bf16* WT = hT + NS * KP * LDZ;                // [NS][KP][LDZ]    B of dh   ([k][feature])
-  __bf16* dzA = WT + NS * KP * LDZ;               // [NS][64][LDZ]    A of dh   ([cell][feature])
+  __bf16* dzA = WT + NS * KP * LDZ;               // [NS][64][LDZ]    (no image any more; with dzT the scratch tile of the row reductions)
   __bf16* dzT = dzA + NS * CB * LDZ;              // [NS][64][LDZ]    A of dW   ([feature][cell])
   float* ytile = (float*)(dzT + NS * FT * LDZ);   // [64][64]
   float* rowv = ytile + CB * FT;                  // [3][64]  per-cell inputs
@@ -367,29 +382,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       // Bernoulli, interior tile with 0/1 labels only: no bounds / NaN / soft-label handling (same algebra)
       const bool ber_fast = IS_BER && (f0 + FT <= g.F) && (c0 + CB <= g.B) && (tflag == 0);
       if (ber_fast) {
-        float su = 0.f, sd = 0.f;
+        // Straight line over pairs of elements (the compiler packs them into v_pk_* forms).  Deferred to the points where
+        // the sums leave the workgroup: the 1 / n of the mean (inv_n) and the (1 - sr) of the per-cell gradient; the
+        // likelihood is summed in log2 units (one v_log per element, no product) and scaled once per tile; bias and
+        // the -log2(e) of the exponential share one fma.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        constexpr float L2E = 1.4426950408889634f;
+        const float nb2 = -bcol * L2E;
+        f2 su2 = {0.f, 0.f}, sd2 = {0.f, 0.f}, ls2 = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int cl = ti * 32 + acc_row(e, lane);
-          float px = sigm_<FAST>(acc[e] + bcol);
-          float sr = rowv[cl];
-          float q = px * sr * fcol;
-          float omq = 1.f - q;
-          float yv = ytile[cl * FT + fl];
-          float arg = (yv == 0.f) ? omq : q;
-          lsum -= fmaxf(log_<FAST>(arg), -100.f);
+        for (int e = 0; e < 16; e += 2) {
+          f2 uu, dd, ll;
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const int cl = ti * 32 + acc_row(e + j, lane);
+            float px;
+            if constexpr (FAST) px = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[e + j], -L2E, nb2)));
+            else px = sigm_<false>(acc[e + j] + bcol);
+            const float sr = rowv[cl];
+            const float q = px * sr * fcol;
+            const float omq = 1.f - q;
+            const float yv = ytile[cl * FT + fl];
+            const float arg = (yv == 0.f) ? omq : q;
+            if constexpr (FAST) ll[j] = fmaxf(__builtin_amdgcn_logf(arg), -100.f * L2E);
+            else ll[j] = fmaxf(logf(arg), -100.f);
+            if (TRAIN) {
+              const float u = div_<FAST>(q - yv, fmaxf(q * omq, 1e-12f)) * q;     // dL/dq * q  (x n)
+              uu[j] = u;
+              dd[j] = u * (1.f - px);
+              dzv[e + j] = dd[j];
+              racc0[e + j] += u;
+            }
+          }
+          ls2 -= ll;
           if (TRAIN) {
-            float u = div_<FAST>(q - yv, fmaxf(q * omq, 1e-12f)) * inv_n * q;     // dL/dq * q
-            float d = u * (1.f - px);
-            dzv[e] = d;
-            racc0[e] += u * (1.f - sr);
-            su += u;
-            sd += d;
+            su2 += uu;
+            sd2 += dd;
           }
         }
+        lsum = (ls2[0] + ls2[1]) * (FAST ? 0.69314718f : 1.f);
         if (TRAIN) {
-          dfs_acc[0] += su * (1.f - fcol);
-          db_acc[0] += sd;
+          dfs_acc[0] += (su2[0] + su2[1]) * (1.f - fcol);
+          db_acc[0] += sd2[0] + sd2[1];
         }
       } else if (MODE == MODE_NB_LOSS && (f0 + FT <= g.F) && (c0 + CB <= g.B)) {
         // NB likelihood pass, interior tile.  Phase 1 treats every label as 0 in straight-line code (the transcendental
@@ -459,10 +493,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
               lsum -= yv * fmaxf(log_<FAST>(q), -100.f) + (1.f - yv) * fmaxf(log_<FAST>(omq), -100.f);
             }
             if (TRAIN) {
-              float dq = div_<FAST>(q - yv, fmaxf(q * omq, 1e-12f)) * inv_n;
+              float dq = div_<FAST>(q - yv, fmaxf(q * omq, 1e-12f));       // inv_n and (1 - sr): applied where the sums leave
               float t1 = dq * px;
               dzv[e] = t1 * sr * fcol * (1.f - px);
-              racc0[e] += t1 * fcol * sr * (1.f - sr);
+              racc0[e] += t1 * fcol * sr;
               dfs_acc[0] += t1 * sr * fcol * (1.f - fcol);
               db_acc[0] += dzv[e];
             }
@@ -502,13 +536,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
               float dap = mu * gmu - scale * T;
               float da = dap * fcol;
               if (g.theta_param)
-                dth_acc[0] += -inv_n * gth * th;
+                dth_acc[0] -= gth * th;
               else
                 da += gth * th;
-              float d = (zz > 0.f) ? -inv_n * da : 0.f;
+              float d = (zz > 0.f) ? -da : 0.f;                 // inv_n: applied where the sums leave the workgroup
               dzv[e] = d;
               db_acc[0] += d;
-              dfs_acc[0] += -inv_n * dap * a_ * fcol * (1.f - fcol);
+              dfs_acc[0] -= dap * a_ * fcol * (1.f - fcol);
             }
           }
         }
@@ -516,12 +550,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       loss_acc += (double)lsum;
       PROF_MARK(7);
       if (TRAIN) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int cl = ti * 32 + acc_row(e, lane);
-          img_put<NS>(dzA, CB, LDZ, cl, fl, dzv[e]);
-        }
-        // dzT[feature][cell]: registers 4q..4q+3 are 4 consecutive cells -> one 8-byte store per term
+        // dzT[feature][cell]: registers 4q..4q+3 are 4 consecutive cells -> one 8-byte store per term.  (No [cell][feature]
+        // image: the dh product reads dzT through the transposing LDS read.)
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
           __bf16 tt[4][3];
@@ -552,7 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             for (int s = 0; s < NS; s++) {
               a[s] = *(const bf16x8*)&dzT[(s * FT + mi * 32 + r) * LDZ + kk * 16 + hq * 8];
               b[s] = *(const bf16x8*)&hT[(s * KP + brow) * LDZ + kk * 16 + hq * 8];
-              a2[s] = *(const bf16x8*)&dzA[(s * CB + mi * 32 + r) * LDZ + kk * 16 + hq * 8];
+              a2[s] = dec_read_tr(dzT + s * FT * LDZ, kk * 16, mi * 32, lane);
               b2[s] = *(const bf16x8*)&WT[(s * KP + brow) * LDZ + kk * 16 + hq * 8];
             }
 #pragma unroll
@@ -595,7 +625,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
           // slab rows are padded to whole cell blocks: one base address, compile-time row offsets, no predicates
           float* dst = g.dh_slab + ((long)blockIdx.x * (ncb * CB) + c0 + mi * 32 + 4 * hq) * KP + k;
 #pragma unroll
-          for (int e = 0; e < 16; e++) dst[((e & 3) + 8 * (e >> 2)) * KP] = accH[e];
+          for (int e = 0; e < 16; e++) dst[((e & 3) + 8 * (e >> 2)) * KP] = accH[e] * inv_n;
         }
       }
     }
@@ -642,6 +672,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         }
       } else {
         float ssum = row_sum();
+        if (MODE == MODE_BER_TRAIN) ssum *= (1.f - rowv[rrow]) * inv_n;     // the factors the epilogue left out
         if (wr) {
           dst[0] = ssum;
           dst[1] = 0.f;
@@ -668,14 +699,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
           for (int e = 0; e < 16; e++) {
             int f = f0 + mi * 32 + acc_row(e, lane);
-            if (f < g.F) g.dW[(long)blockIdx.y * g.cg_stride_w + (long)f * g.lddw + k] = accW[t][e];
+            if (f < g.F) g.dW[(long)blockIdx.y * g.cg_stride_w + (long)f * g.lddw + k] = accW[t][e] * inv_n;
           }
         }
       }
       // per-feature sums: lanes (r, hq=0/1) of waves (ti=0/1, tj) hold partials of feature tj*32+r
-      float v0 = db_acc[t] + __shfl_xor(db_acc[t], 32, 64);
-      float v1 = dfs_acc[t] + __shfl_xor(dfs_acc[t], 32, 64);
-      float v2 = dth_acc[t] + __shfl_xor(dth_acc[t], 32, 64);
+      float v0 = (db_acc[t] + __shfl_xor(db_acc[t], 32, 64)) * inv_n;
+      float v1 = (dfs_acc[t] + __shfl_xor(dfs_acc[t], 32, 64)) * inv_n;
+      float v2 = (dth_acc[t] + __shfl_xor(dth_acc[t], 32, 64)) * inv_n;
       if (hq == 0) {
         cred[((ti * NPT + t) * 3 + 0) * FT + tj * 32 + r] = v0;
         cred[((ti * NPT + t) * 3 + 1) * FT + tj * 32 + r] = v1;
