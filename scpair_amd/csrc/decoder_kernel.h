@@ -80,13 +80,17 @@ __device__ __forceinline__ void img_put(__bf16* img, int rows, int ld, int row, 
 // columns 4p..4p+3), so dZ^T -- written once, as the weight gradient's operand -- also serves the dh product.
 // EXEC must be all ones (callers branch wave-uniformly).
 typedef __attribute__((ext_vector_type(4))) short dec_short4;
+// bf16 elements of the dZ^T image region: NS images of [64][LDZ], at least the [64][65] floats of the row-reduction tile
+template <int NS> constexpr int dec_dz_elems() { return (NS * FT * LDZ * 2 >= CB * 65 * 4) ? NS * FT * LDZ : CB * 65 * 2; }
+
+template <int LD = LDZ>
 __device__ __forceinline__ bf16x8 dec_read_tr(const __bf16* img, int k0, int m0, int lane) {
   const int g = lane >> 5, mb = ((lane >> 4) & 1) * 16, q = (lane & 15) >> 2, p = lane & 3;
   typedef __attribute__((address_space(3))) dec_short4 lds_s4;
-  const __bf16* a = img + (k0 + 8 * g + q) * LDZ + m0 + mb + 4 * p;
+  const __bf16* a = img + (k0 + 8 * g + q) * LD + m0 + mb + 4 * p;
   union { dec_short4 h[2]; bf16x8 v; } u;
   u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)a);
-  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(a + 4 * LDZ));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(a + 4 * LD));
   return u.v;
 }
 
@@ -98,14 +102,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   constexpr int LDK_ = KP + 8;
   constexpr int NTK = (KP + 31) / 32;      // 32-wide column tiles covering K
   constexpr bool FAST = (NS == 1);
+  constexpr int DZ_ELEMS = dec_dz_elems<NS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* hA = (__bf16*)smem_raw;                 // [NS][64][LDK_]   A of Z
-  __bf16* WB = hA + NS * CB * LDK_;               // [NS][64][LDK_]   B of Z
-  __bf16* hT = WB + NS * FT * LDK_;               // [NS][KP][LDZ]    B of dW   ([k][cell])
-  __bf16* WT = hT + NS * KP * LDZ;                // [NS][KP][LDZ]    B of dh   ([k][feature])
-  __bf16* dzA = WT + NS * KP * LDZ;               // [NS][64][LDZ]    (no image any more; with dzT the scratch tile of the row reductions)
-  __bf16* dzT = dzA + NS * CB * LDZ;              // [NS][64][LDZ]    A of dW   ([feature][cell])
-  float* ytile = (float*)(dzT + NS * FT * LDZ);   // [64][64]
+  __bf16* hA = (__bf16*)smem_raw;                 // [NS][64][LDK_]   A of Z; B of dW through the transposing read
+  __bf16* WB = hA + NS * CB * LDK_;               // [NS][64][LDK_]   B of Z; B of dh through the transposing read
+  __bf16* dzT = WB + NS * FT * LDK_;              // [NS][64][LDZ]    A of dW ([feature][cell]); A of dh through the
+                                                  // transposing read; also the scratch tile rt[64][65] of the row reductions
+  float* ytile = (float*)(dzT + DZ_ELEMS);        // [64][64]
   float* rowv = ytile + CB * FT;                  // [3][64]  per-cell inputs
   float* rred = rowv + 3 * CB;                    // [2][2][64] per-cell partial reductions
   float* cred = ytile;                            // [2][NPT][3][64] per-feature partials; aliases ytile (used after the loops)
@@ -196,9 +199,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     if (!IS_BER && MODE != MODE_NB_STATS && g.rowlse) row_n[1] = g.rowlse[cc];
     if (MODE == MODE_NB_GRAD && g.rowT) row_n[2] = g.rowT[cc];
   };
-  // registers -> row-major image [NS][64][LDK_] (8-byte stores) and, when training, the transposed image [NS][KP][LDZ];
-  // rows past the end and the K-padding columns arrive as zeros from either load path
-  auto put_rows = [&](const float* reg, __bf16* img, __bf16* imgT) {
+  // registers -> row-major image [NS][64][LDK_] (8-byte stores); rows past the end and the K-padding columns arrive as
+  // zeros from either load path.  No transposed images: the dW / dh products read these through the transposing LDS
+  // read (columns past KP hold whatever lies there and only reach output columns >= K, which are never stored)
+  auto put_rows = [&](const float* reg, __bf16* img) {
     __bf16 tt[KQ][3];
 #pragma unroll
     for (int i = 0; i < KQ; i++) bf16_split<NS>(reg[i], tt[i]);
@@ -210,10 +214,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
         for (int j = 0; j < 4; j++) o[j] = tt[4 * i + j][s2];
         *(bf16x4*)&img[(s2 * 64 + sp) * LDK_ + sq * KQ + 4 * i] = o;
-      }
-      if (TRAIN) {
-#pragma unroll
-        for (int i = 0; i < KQ; i++) imgT[(s2 * KP + sq * KQ + i) * LDZ + sp] = tt[i][s2];
       }
     }
   };
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       PROF_MARK(1);
       if (t == 0) {
         // ---- h block (both layouts) and the per-cell inputs, from the prefetch registers ---------------
-        put_rows(hreg, hA, hT);
+        put_rows(hreg, hA);
         if (tid < CB) {
           const bool ok = c0 + tid < g.B;
           if (IS_BER) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         }
       }
       // ---- W tile (both layouts) from the prefetch registers, clear label tile ---------------------
-      put_rows(wreg, WB, WT);
+      put_rows(wreg, WB);
       const float bias_c = bias_n, fs_c = fs_n, th_c = th_n;      // this tile's scalars, before the next prefetch
       if (NEED_LABELS) {
         if (!TRAIN) {
@@ -573,17 +573,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         // ---- dW tile += dZ^T h ; dh block += dZ W -----------------------------------------------
         const int mi = wave & 1, nj = wave >> 1;
         if (nj < NTK) {
-          int brow = nj * 32 + r;
-          if (brow >= KP) brow = 0;
 #pragma unroll
           for (int kk = 0; kk < CB / 16; kk++) {
             bf16x8 a[NS], b[NS], a2[NS], b2[NS];
 #pragma unroll
             for (int s = 0; s < NS; s++) {
               a[s] = *(const bf16x8*)&dzT[(s * FT + mi * 32 + r) * LDZ + kk * 16 + hq * 8];
-              b[s] = *(const bf16x8*)&hT[(s * KP + brow) * LDZ + kk * 16 + hq * 8];
+              b[s] = dec_read_tr<LDK_>(hA + s * CB * LDK_, kk * 16, nj * 32, lane);
               a2[s] = dec_read_tr(dzT + s * FT * LDZ, kk * 16, mi * 32, lane);
-              b2[s] = *(const bf16x8*)&WT[(s * KP + brow) * LDZ + kk * 16 + hq * 8];
+              b2[s] = dec_read_tr<LDK_>(WB + s * FT * LDK_, kk * 16, nj * 32, lane);
             }
 #pragma unroll
             for (int sa = 0; sa < NS; sa++)
@@ -633,7 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       // Row reductions over the 64 feature columns of the chunk's tiles: the per-lane partials go through an LDS
       // tile rt[cell][65] (odd stride: conflict-free both ways; it reuses the dZ images, idle here) and are summed
       // by 4 threads per cell in a fixed order.
-      float* rt = (float*)dzA;
+      float* rt = (float*)dzT;
       const int rrow = tid >> 2, rq = tid & 3;
       auto row_sum = [&]() {
         float a = 0.f;
@@ -738,7 +736,7 @@ template <int MODE> constexpr int dec_npt() { return (MODE == MODE_BER_TRAIN || 
 
 template <int NS, int KP>
 static size_t dec_smem() {
-  size_t bf = (size_t)NS * ((size_t)CB * (KP + 8) * 2 + (size_t)KP * LDZ * 2 + (size_t)CB * LDZ * 2);
+  size_t bf = (size_t)NS * ((size_t)CB * (KP + 8) * 2) + (size_t)dec_dz_elems<NS>();
   return bf * sizeof(__bf16) + sizeof(float) * (CB * FT + 3 * CB + 4 * CB);
 }
 
