@@ -43,6 +43,49 @@ PRESETS = {
 XGMI_PEAK_GBS = 7 * 153.0          # MI355X: 7 xGMI links x ~153 GB/s per GPU (MI355X_MICROARCH.md)
 
 
+VALU_LANE_RATE = 256 * 4 * 16          # fp32 lanes per clock, whole chip: 256 CUs x 4 SIMDs x 16 lanes (a wave64 instruction = 4 cycles)
+CLOCK_GHZ = 2.4                        # MI355X peak engine clock (MI355X_MICROARCH.md); the sustained clock under load is lower
+
+
+def decoder_roofline(a, dec_ev, n_roof):
+    """VALU-issue bound of the fused decoders (K5-K8: no HBM or MFMA roofline applies -- the logits never leave the CU and
+    the K <= 64 products keep the matrix pipes under 10 % busy).  Bound = vector instructions the kernels retire
+    (SQ_INSTS_VALU of a separate rocprofv3 --pmc pass over this command, stored in profiles/) x 4 cycles per wave64
+    instruction, + 12 more cycles for every quarter-rate transcendental, over 1024 SIMDs at the peak clock.  `achieved`
+    = elements per second of the decoder entry points (their passes + finishing launches, HIP events)."""
+    if not dec_ev:
+        return None
+    stored = None
+    try:
+        with open(os.path.join(ROOT, "profiles", f"r03_{a.workload.lower()}_decoder_valu.json")) as fh:
+            stored = json.load(fh)
+        if (stored.get("batch"), stored.get("genes"), stored.get("peaks")) != (a.batch, a.genes, a.peaks) or a.precision != "bf16":
+            stored = None
+    except (OSError, ValueError):
+        stored = None
+    out = []
+    for kind, passes, what in (("ber", 1, "Bernoulli decoder (scp_ber_dec_bce: dec_kernel<BER_TRAIN> + finishing launch)"),
+                               ("nb", 3, "NB decoder (scp_nb_dec_ll: dec_kernel<NB_STATS / NB_LOSS / NB_GRAD> + 3 finishing launches)")):
+        ev = [e for e in dec_ev if e[2] == kind and e[6]]
+        if not ev:
+            continue
+        ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev) / n_roof
+        elems = sum(b_ * f_ for _, _, _, b_, f_, _, _ in ev) / n_roof          # label elements per step (each visited `passes` times)
+        ent = {"kernel": what, "bound": "valu", "elements_per_step": elems, "passes": passes, "avg_ms_per_step": ms,
+               "achieved": elems / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "unit": "G elements/s", "peak": None, "frac": None}
+        st = (stored or {}).get("kernels", {}).get(kind)
+        if st and ms > 0:
+            cyc = (st["insts_valu"] * 4.0 + st["transcendentals_per_element"] * (elems / 64.0) * 12.0) / (256 * 4)
+            floor_ms = cyc / (CLOCK_GHZ * 1e9) * 1e3
+            ent.update({"valu_instructions_per_element": st["insts_valu"] / (elems / 64.0),
+                        "transcendentals_per_element": st["transcendentals_per_element"],
+                        "issue_floor_ms": floor_ms, "peak": elems / (floor_ms * 1e-3) / 1e9, "frac": floor_ms / ms,
+                        "lds_bank_conflict_share": st.get("lds_bank_conflict_share"),
+                        "counters_source": f"stored: profiles/r03_{a.workload.lower()}_decoder_valu.json ({stored.get('command')})"})
+        out.append(ent)
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -535,9 +578,12 @@ def main():
     if fuse or (sharded and A.fused):
         S.ops.set_fused_timer(fused_ev)
     n_roof = max(a.roofline_steps, 1)
+    dec_ev = []
+    S.ops.set_decoder_timer(dec_ev)
     for _ in range(n_roof):
         step(time_it=True, side_=None)
     S.ops.set_fused_timer(None)
+    S.ops.set_decoder_timer(None)
     barrier()
 
     # ---- candidates for the dominant kernel; `roofline` = the one with the most time per step ----------------------
@@ -589,6 +635,9 @@ def main():
         except (OSError, KeyError, ValueError, TypeError):
             pass
     roof.pop("_kind", None)
+    dec_roof = decoder_roofline(a, dec_ev, n_roof)
+    if dec_roof:
+        roof["decoders"] = dec_roof
     if exch_ev:
         x_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in exch_ev)
         x_bytes = sum(nb for _, _, nb in exch_ev)

@@ -29,12 +29,14 @@ buf = (C.c_ulonglong * n)()
 rc = L.scp_dec_prof_read(buf, n)
 a = np.array(buf[:], dtype=np.int64).reshape(-1, 12)
 a = a[a[:, 0] > 0]
-names = ["B1 wait", "stage W/h + clear", "B2 wait", "scatter + issue", "B3 wait", "Z mfma", "epilogue", "dz writes", "B4 wait",
-         "dW/dh mfma + rotate"]
-print("scatter only (mark 3 -> 11):", (a[1:, 11] - a[1:, 3]).mean(), " issue (11 -> 4):", (a[1:, 4] - a[1:, 11]).mean())
-d = np.diff(a[:, :11], axis=1)
+seq = [0, 1, 3, 11, 4, 5, 6, 7, 8, 9, 10]        # order of the marks inside a training iteration (mark 2: eval passes only)
+names = ["B1 wait", "stage W/h", "scatter labels", "issue next loads", "B3 wait", "Z mfma", "epilogue", "dz writes", "B4 wait",
+         "clear + dW/dh mfma"]
 print("iterations recorded", len(a), "rc", rc)
 for i, nm in enumerate(names):
-    print("%-22s mean %7.0f   even-t %7.0f   odd-t %7.0f" % (nm, d[1:, i].mean(), d[2::2, i].mean(), d[1::2, i].mean()))
+    d = a[1:, seq[i + 1]] - a[1:, seq[i]]
+    print("%-22s mean %7.0f   even-t %7.0f   odd-t %7.0f" % (nm, d.mean(), d[1::2].mean(), d[0::2].mean()))
+tail = a[1:, 0][1:] - a[1:, 10][:-1]
+print("%-22s mean %7.0f   (rotate; block end after odd tiles: row reductions, dh slab)" % ("loop end -> next top", tail.mean()))
 tot = (a[1:, 0] - a[:-1, 0])
 print("iteration period mean", tot.mean(), "even->odd", tot[0::2].mean(), "odd->even (block end)", tot[1::2].mean())

@@ -59,4 +59,45 @@ with open("$OUT/prof_sq_counters.txt", "w") as fh:
         fh.write(f"{n:46s} " + " ".join(f"{m[c]:14.3g}" for c in cnt) + f" {busy:10.3f} {vw:10.3f}\n")
 PY
 rm -rf $OUT/pmc
+# second counter pass: LDS activity of every kernel + the decoders' retired vector instructions -> prof_decoder_valu.json
+# (what bench.py's roofline.decoders prices the VALU-issue bound with)
+CNT2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32"
+timeout -s KILL 240 rocprofv3 --pmc $CNT2 --output-format csv -d $OUT/pmc2 -o pmc -- python3 bench.py --cpu-steps 0 --steps 4 --warmup 2 --roofline-steps 0 --streams 1 --no-extras > /dev/null 2> $OUT/prof_pmc2.err
+echo "pmc2 done"
+python3 - <<PY
+import csv, glob, collections, json
+f = glob.glob("$OUT/pmc2/**/*counter_collection.csv", recursive=True)[0]
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(f)):
+    full = r["Kernel_Name"]
+    if "at::" in full or "rocprim" in full or "rocclr" in full:
+        continue
+    agg.setdefault(full.split("(")[0], collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+def mean(d, c):
+    v = d.get(c, [])[-2:]
+    return sum(v) / len(v) if v else 0.0
+with open("$OUT/prof_lds_counters.txt", "w") as fh:
+    fh.write("rocprofv3 --pmc $CNT2 -- python3 bench.py --cpu-steps 0 --steps 4 --warmup 2 --roofline-steps 0 --streams 1 --no-extras  (means of the last two launches)\n")
+    fh.write(f"{'kernel':50s} {'INSTS_VALU':>12s} {'VALU_TRANS':>12s} {'INSTS_LDS':>12s} {'LDS_IDX_ACT':>12s} {'BANK_CONFL':>12s} {'conflict share':>15s}\n")
+    for n, d in agg.items():
+        act, bc = mean(d, "SQ_LDS_IDX_ACTIVE"), mean(d, "SQ_LDS_BANK_CONFLICT")
+        fh.write(f"{n[-50:]:50s} {mean(d, 'SQ_INSTS_VALU'):12.4g} {mean(d, 'SQ_INSTS_VALU_TRANS_F32'):12.4g} {mean(d, 'SQ_INSTS_LDS'):12.4g} {act:12.4g} {bc:12.4g} {(bc / act if act else 0.0):15.3f}\n")
+B, G, P = 1024, 20000, 100000
+kern = {"ber": {"names": ["dec_kernel<1, 48, 2, 0, true>"], "elements": B * P, "trans_src": 4.0},
+        "nb": {"names": ["dec_kernel<1, 48, 4, 2, true>", "dec_kernel<1, 48, 4, 3, true>", "dec_kernel<1, 48, 2, 4, true>"], "elements": B * G,
+               "trans_src": 2.0 + 5.3 + 6.3}}
+out = {"workload": "C2", "batch": B, "genes": G, "peaks": P, "command": "rocprofv3 --pmc $CNT2 -- python3 bench.py --cpu-steps 0 --steps 4 --warmup 2 --roofline-steps 0 --streams 1 --no-extras",
+       "note": "insts_valu = SQ_INSTS_VALU per step summed over the entry point's dec_kernel passes (wave64 instructions, whole chip); transcendentals_per_element = SQ_INSTS_VALU_TRANS_F32 x 64 / label elements when that counter reports, else counted in the source (exp, log, rcp per element, summed over the passes)", "kernels": {}}
+for k, spec in kern.items():
+    iv = tr = act = bc = 0.0
+    for n, d in agg.items():
+        if any(n.endswith(x) for x in spec["names"]):
+            iv += mean(d, "SQ_INSTS_VALU"); tr += mean(d, "SQ_INSTS_VALU_TRANS_F32"); act += mean(d, "SQ_LDS_IDX_ACTIVE"); bc += mean(d, "SQ_LDS_BANK_CONFLICT")
+    if iv:
+        out["kernels"][k] = {"insts_valu": iv, "transcendentals_per_element": (tr * 64.0 / spec["elements"]) if tr else spec["trans_src"],
+                             "transcendentals_from": "SQ_INSTS_VALU_TRANS_F32" if tr else "source count",
+                             "lds_bank_conflict_share": (bc / act if act else None)}
+json.dump(out, open("$OUT/prof_decoder_valu.json", "w"), indent=1)
+PY
+rm -rf $OUT/pmc2
 echo "all done"

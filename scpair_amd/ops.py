@@ -15,7 +15,7 @@ from .sparse import BatchTiles
 
 import os as _os
 
-_cfg = {"ns": 3, "seed_ctr": 0, "fused_timer": None, "fwd_wgs": int(_os.environ.get("SCPAIR_FWD_WGS", "256"))}
+_cfg = {"ns": 3, "seed_ctr": 0, "fused_timer": None, "decoder_timer": None, "fwd_wgs": int(_os.environ.get("SCPAIR_FWD_WGS", "256"))}
 
 
 def set_precision(mode: str):
@@ -40,6 +40,12 @@ def set_fused_timer(sink):
     sparse first layers (operand_bytes = the tile-list entries and the bf16 dY^T the launch reads); "wgemm_adamw": a wide
     plain layer (operand_bytes = the bf16 dy and x operands)."""
     _cfg["fused_timer"] = sink
+
+
+def set_decoder_timer(sink):
+    """Diagnostic: a list that receives (start_event, end_event, kind, B, F, K, train) for every call of a fused decoder
+    entry point (kind "ber": scp_ber_dec_bce, "nb": scp_nb_dec_ll; each call = its passes + finishing launches), or None."""
+    _cfg["decoder_timer"] = sink
 
 
 def set_seed_rank(rank: int):
@@ -1223,11 +1229,18 @@ class BerDecoderLossFn(torch.autograd.Function):
             dh = torch.empty((Bn, K), dtype=torch.float32, device=dev)
             dfs = torch.empty(F, dtype=torch.float32, device=dev) if fsc is not None else None
             dl = torch.empty(Bn, dtype=torch.float32, device=dev) if lrow_n == Bn else None
+        tm = _cfg["decoder_timer"]
+        if tm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(L.scp_ber_dec_bce(int(train), Bn, F, K, h.data_ptr(), K, Wc.data_ptr(), K, bc.data_ptr(),
                                      _lib.ptr(fsc), _lib.ptr(lr), lrow_n, _lib.ptr(tiles.ptr), _lib.ptr(tiles.key),
                                      _lib.ptr(tiles.val), _lib.ptr(tiles.nnan), None, loss.data_ptr(), _lib.ptr(dW), K,
                                      _lib.ptr(db), _lib.ptr(dfs), _lib.ptr(dh), K, _lib.ptr(dl), ws_f.data_ptr(),
                                      ws_d.data_ptr(), _ns(), _lib.stream()), "scp_ber_dec_bce")
+        if tm is not None:
+            e1.record()
+            tm.append((e0, e1, "ber", Bn, F, K, train))
         ctx.grads = (dh, dW, db, dfs, dl)
         ctx.lshape = None if lrow is None else lrow.shape
         return loss.reshape(())
@@ -1276,11 +1289,18 @@ class NbDecoderLossFn(torch.autograd.Function):
             dfs = torch.empty(F, dtype=torch.float32, device=dev) if fsc is not None else None
             dth = torch.empty(F, dtype=torch.float32, device=dev) if thp is not None else None
             dlat = torch.empty(Bn, dtype=torch.float32, device=dev) if latc is not None else None
+        tm = _cfg["decoder_timer"]
+        if tm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(L.scp_nb_dec_ll(int(train), Bn, F, K, h.data_ptr(), K, Wc.data_ptr(), K, bc.data_ptr(), _lib.ptr(fsc),
                                    _lib.ptr(thp), Lr.data_ptr(), _lib.ptr(latc), _lib.ptr(tiles.ptr), _lib.ptr(tiles.key),
                                    _lib.ptr(tiles.val), None, loss.data_ptr(), _lib.ptr(dW), K, _lib.ptr(db),
                                    _lib.ptr(dfs), _lib.ptr(dth), _lib.ptr(dh), K, _lib.ptr(dlat), rowbuf.data_ptr(),
                                    ws_f.data_ptr(), ws_d.data_ptr(), _ns(), _lib.stream()), "scp_nb_dec_ll")
+        if tm is not None:
+            e1.record()
+            tm.append((e0, e1, "nb", Bn, F, K, train))
         ctx.grads = (dh, dW, db, dfs, dth, dlat)
         ctx.latshape = None if lat is None else lat.shape
         return loss.reshape(())
