@@ -12,6 +12,10 @@
  *   - `ns` selects MFMA input precision: 1 = bf16 inputs, 3 = bf16 hi+mid+lo split of every fp32
  *     operand (6 MFMAs per product, fp32-equivalent); accumulation is always fp32
  *   - a "tile list" (t_ptr, t_key, t_val) is the minibatch re-bucketing built by scp_tiles_build
+ *   - multi-GPU: there is no communication entry point.  The gradient exchange (SURVEY.md 8b sketched an
+ *     scp_allreduce_bucket) is torch.distributed on RCCL, called from Python (scpair_amd/distributed.py): a C wrapper
+ *     would only forward to the same RCCL call and put communicator handles into this ABI.  The kernels' side of it is
+ *     here: scp_spmm_dw_bf16_g16 writes gradients straight into the exchange buffer, scp_adamw_multi reads them (g_bf16).
  */
 #ifndef SCPAIR_HIP_H
 #define SCPAIR_HIP_H
