@@ -196,9 +196,26 @@ typedef struct {
   float* dW1c; long lddw1c;
   int adam; float *adam_m, *adam_v; void* adam_sh; long adam_ldsh;
   float lr, wd, beta1, beta2, adam_eps, bc1, bc2, gscale; const float* bc_dev;
+  /* BatchNorm1d behind each activation (FCNN built with batchnorm=True, utils.py:61-62: Linear -> LayerNorm -> act ->
+   * BatchNorm1d -> Dropout); bn = 0: none.  bn_train != 0: statistics of the batch (biased variance), running mean / var
+   * updated in place with momentum bn_mom (unbiased variance), as nn.BatchNorm1d in training mode; else the running
+   * statistics normalise.  Affine weight / bias and the running tensors are nullable (affine=False,
+   * track_running_stats=False).  Batch statistics need the whole batch between the activation and the dropout of a
+   * layer, so the calls run the tail in three segments with a column-statistics kernel between them (forward) and
+   * three segments with a column-sum kernel between them (backward); the segments hand over through xhat1 / xhat2
+   * (required whenever bn_train != 0, also without a backward) and through bn_dy1 [B][H1].
+   * bn_ws: scp_enc_tail_bn_ws_floats(H1, H2) floats (scale, shift, mean, rstd and the backward's column sums of both
+   * layers), kept between the forward and the backward call of a step.  All branches of a call share bn / bn_train. */
+  int bn, bn_train;
+  const float *bn1_w, *bn1_b; float *bn1_rm, *bn1_rv;      /* [H1] */
+  const float *bn2_w, *bn2_b; float *bn2_rm, *bn2_rv;      /* [H2] */
+  float bn_eps1, bn_eps2, bn_mom1, bn_mom2;
+  float *bn_ws, *bn_dy1;
+  float *dbn1_w, *dbn1_b, *dbn2_w, *dbn2_b;                /* backward: gradients of the affine parameters (nullable) */
 } ScpEncTail;
 int scp_enc_tail_fwd(const ScpEncTail* branches, int nbranch, void* stream);
 long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3, int C);
+long scp_enc_tail_bn_ws_floats(int H1, int H2);
 int scp_enc_tail_bwd(const ScpEncTail* branches, int nbranch, void* stream);
 
 /* ---- Bernoulli decoder + BCE, fused forward(+backward): Output_Module_Ber.forward (model.py:164-190)

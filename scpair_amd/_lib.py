@@ -42,7 +42,13 @@ class EncTail(C.Structure):
                 ("cov", P), ("ldcov", L), ("C", I), ("W1c", P), ("ldw1c", L), ("dW1c", P), ("lddw1c", L),
                 ("adam", I), ("adam_m", P), ("adam_v", P), ("adam_sh", P), ("adam_ldsh", L),
                 ("lr", F), ("wd", F), ("beta1", F), ("beta2", F), ("adam_eps", F), ("bc1", F), ("bc2", F), ("gscale", F),
-                ("bc_dev", P)]
+                ("bc_dev", P),
+                ("bn", I), ("bn_train", I),
+                ("bn1_w", P), ("bn1_b", P), ("bn1_rm", P), ("bn1_rv", P),
+                ("bn2_w", P), ("bn2_b", P), ("bn2_rm", P), ("bn2_rv", P),
+                ("bn_eps1", F), ("bn_eps2", F), ("bn_mom1", F), ("bn_mom2", F),
+                ("bn_ws", P), ("bn_dy1", P),
+                ("dbn1_w", P), ("dbn1_b", P), ("dbn2_w", P), ("dbn2_b", P)]
 
 
 _SIGS = {
@@ -80,6 +86,7 @@ _SIGS = {
     "scp_ln_act_bwd": (I, [P, L, P, L, P, P, P, I, I, F, F, U64, P, P, L, P, P, P, P, P]),
     "scp_enc_tail_fwd": (I, [C.POINTER(EncTail), I, P]),
     "scp_enc_tail_ws_floats": (L, [I, I, I, I, I]),
+    "scp_enc_tail_bn_ws_floats": (L, [I, I]),
     "scp_enc_tail_bwd": (I, [C.POINTER(EncTail), I, P]),
     "scp_dec_chunks": (I, [I]),
     "scp_dec_kp": (I, [I]),

@@ -125,6 +125,21 @@ static __host__ __device__ inline TailWs tail_ws(int B, int H1, int H2, int N3, 
   return w;
 }
 
+// Layout of a branch's BatchNorm workspace (ScpEncTail.bn_ws): per layer scale = w * rstd, shift = b - mean * scale, mean,
+// rstd (written by the forward's column-statistics kernel, read again by the backward) and the backward's column sums
+// S1 = sum_cells dy, S2 = sum_cells dy * xhat_bn.  The H2-wide vectors are padded to multiples of 4.
+struct BnOff {
+  int sc1, sh1, mu1, rs1, s1a, s2a, sc2, sh2, mu2, rs2, s1b, s2b, total;
+};
+static __host__ __device__ inline BnOff bn_off(int H1, int H2) {
+  BnOff o;
+  const int h2p = (H2 + 3) / 4 * 4;
+  o.sc1 = 0; o.sh1 = H1; o.mu1 = 2 * H1; o.rs1 = 3 * H1; o.s1a = 4 * H1; o.s2a = 5 * H1;
+  o.sc2 = 6 * H1; o.sh2 = o.sc2 + h2p; o.mu2 = o.sh2 + h2p; o.rs2 = o.mu2 + h2p; o.s1b = o.rs2 + h2p; o.s2b = o.s1b + h2p;
+  o.total = o.s2b + h2p;
+  return o;
+}
+
 // W3 [N3][H2] and b3 into LDS as [n][65] + [64]; every thread of the workgroup takes part
 __device__ __forceinline__ void stage_w3(const ScpEncTail& m, float* W3s, int tid, int nthreads) {
   const int nw = m.N3 * m.H2;
@@ -136,8 +151,11 @@ __device__ __forceinline__ void stage_w3(const ScpEncTail& m, float* W3s, int ti
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NCH>
-__global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) {
+// BN (batchnorm=True encoders): `seg` selects a segment of the tail -- 0: all of it, BatchNorm applied with the scale /
+// shift vectors in bn_ws (running statistics); 1: slabs -> xhat1, rstd1; 2: xhat1 -> BatchNorm 1, dropout, second layer ->
+// xhat2, rstd2; 3: xhat2 -> BatchNorm 2, dropout, final Linear -> out.  The column-statistics kernel runs between them.
+template <int NCH, bool BN>
+__global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S, int seg) {
   __shared__ float W3s[64 * 65 + 64];
   const ScpEncTail& m = S.b[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -163,6 +181,22 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
     live[r] = row0 + r < B;
     rowc[r] = min(row0 + r, B - 1);               // cells past the batch end recompute the last one and store nothing
   }
+  f4 a[ET_RW][NCH];
+  const int zc = lane & (ET_RW - 1), q = lane >> ET_LG;      // narrow layout: my cell, my column residue
+  const int rowz = min(row0 + zc, B - 1);
+  const bool livez = row0 + zc < B;
+  float zr[ET_RW];
+  bool vz[ET_RW];
+  int jc[ET_RW];
+  float xh2[ET_RW];
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) {
+    vz[i] = ET_QN * i + q < H2;
+    jc[i] = min(ET_QN * i + q, H2 - 1);
+  }
+  [[maybe_unused]] const BnOff bo = bn_off(H1, H2);
+  if (!BN || seg != 3) {
+  if (!BN || seg < 2) {
   f4 v[ET_RW][NCH];
   f4 gam[NCH], bet[NCH];                          // issued ahead of the slab loads: nothing later waits on them alone
 #pragma unroll
@@ -247,7 +281,6 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
     part[r] = q;
   }
   const float qsum = reduce_rw<ET_RW>(part, lane);
-  f4 a[ET_RW][NCH];
 #pragma unroll
   for (int r = 0; r < ET_RW; r++) {
     const float rstd1 = 1.f / sqrtf(lane_bcast(qsum, r) / (float)H1 + m.eps1);
@@ -256,17 +289,43 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
     for (int c = 0; c < NCH; c++) {
       const f4 xh = (v[r][c] - mean1[r]) * rstd1;
       if (m.xhat1 && ok[c] && live[r]) *(f4*)(m.xhat1 + (long)rowc[r] * H1 + ko[c]) = xh;
-      const f4 z = xh * gam[c] + bet[c];
-      const f4 t = leaky4(z, m.slope) * keep4(sd1, (uint64_t)rowc[r] * H1 + ko[c], m.p1);
-      a[r][c] = ok[c] ? t : zero4;
+      if constexpr (BN) {
+        a[r][c] = xh;                              // activation, BatchNorm and dropout follow below
+      } else {
+        const f4 z = xh * gam[c] + bet[c];
+        const f4 t = leaky4(z, m.slope) * keep4(sd1, (uint64_t)rowc[r] * H1 + ko[c], m.p1);
+        a[r][c] = ok[c] ? t : zero4;
+      }
+    }
+  }
+  if (BN && seg == 1) return;                     // the column statistics of the activations come next
+  }  // seg < 2
+  if constexpr (BN) {
+    f4 gam[NCH], bet[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      gam[c] = *(const f4*)(m.g1 + ko[c]);
+      bet[c] = *(const f4*)(m.be1 + ko[c]);
+    }
+    if (seg == 2) {
+#pragma unroll
+      for (int r = 0; r < ET_RW; r++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a[r][c] = *(const f4*)(m.xhat1 + (long)rowc[r] * H1 + ko[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const f4 sc = *(const f4*)(m.bn_ws + bo.sc1 + ko[c]), sh = *(const f4*)(m.bn_ws + bo.sh1 + ko[c]);
+#pragma unroll
+      for (int r = 0; r < ET_RW; r++) {
+        const f4 z = a[r][c] * gam[c] + bet[c];
+        const f4 t = (leaky4(z, m.slope) * sc + sh) * keep4(sd1, (uint64_t)rowc[r] * H1 + ko[c], m.p1);
+        a[r][c] = ok[c] ? t : zero4;
+      }
     }
   }
   // second layer: z2[cell][j] = a1[cell] . W2[j] + b2[j]; the wave streams the rows of W2 (independent loads, four
   // rows in flight) and forms the four cells' dot products with each
-  const int zc = lane & (ET_RW - 1), q = lane >> ET_LG;      // narrow layout: my cell, my column residue
-  const int rowz = min(row0 + zc, B - 1);
-  const bool livez = row0 + zc < B;
-  float zr[ET_RW];
 #pragma unroll
   for (int i = 0; i < ET_RW; i++) zr[i] = 0.f;
 #pragma unroll
@@ -315,14 +374,9 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
       zr[jb] = zk;
     }
   }
-  bool vz[ET_RW];
-  int jc[ET_RW];
-  float xh2[ET_RW];
   float s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < ET_RW; i++) {
-    vz[i] = ET_QN * i + q < H2;
-    jc[i] = min(ET_QN * i + q, H2 - 1);
     zr[i] = vz[i] ? zr[i] + m.b2[jc[i]] : 0.f;
     s2 += zr[i];
   }
@@ -335,12 +389,22 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
   }
   const float rstd2 = 1.f / sqrtf(cell_sum<ET_RW>(q2) / (float)H2 + m.eps2);
   if (q == 0 && m.rstd2 && livez) m.rstd2[rowz] = rstd2;
-  float x2[ET_RW];
 #pragma unroll
   for (int i = 0; i < ET_RW; i++) {
     xh2[i] *= rstd2;
     if (m.xhat2 && vz[i] && livez) m.xhat2[(long)rowz * H2 + jc[i]] = xh2[i];
-    const float t = leaky_(xh2[i] * m.g2[jc[i]] + m.be2[jc[i]], m.slope) * keep_scale(sd2, (uint64_t)rowz * H2 + jc[i], m.p2);
+  }
+  if (BN && seg == 2) return;                     // column statistics of the second layer's activations come next
+  } else {   // BN, seg == 3
+#pragma unroll
+    for (int i = 0; i < ET_RW; i++) xh2[i] = vz[i] ? m.xhat2[(long)rowz * H2 + jc[i]] : 0.f;
+  }
+  float x2[ET_RW];
+#pragma unroll
+  for (int i = 0; i < ET_RW; i++) {
+    float t = leaky_(xh2[i] * m.g2[jc[i]] + m.be2[jc[i]], m.slope);
+    if constexpr (BN) t = t * m.bn_ws[bo.sc2 + jc[i]] + m.bn_ws[bo.sh2 + jc[i]];
+    t *= keep_scale(sd2, (uint64_t)rowz * H2 + jc[i], m.p2);
     x2[i] = vz[i] ? t : 0.f;
   }
   if (N3 == 0) {
@@ -387,8 +451,11 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_fwd_kernel(TailSet S) 
   }
 }
 
-template <int NCH>
-__global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) {
+// BN: `seg` selects a segment of the backward -- 1: dOut -> final Linear, dropout 2 -> dy2 (left in the dz2 buffer);
+// 2: dy2 -> BatchNorm 2, activation, LayerNorm 2 -> dz2, second Linear, dropout 1 -> dy1 (bn_dy1); 3: dy1 -> BatchNorm 1,
+// activation, LayerNorm 1 -> dY1 / dYT.  The column-sum kernel (S1, S2 of the BatchNorm backward) runs between them.
+template <int NCH, bool BN>
+__global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S, int seg) {
   __shared__ float W3s[64 * 65 + 64];
   const ScpEncTail& m = S.b[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -401,6 +468,7 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
   const int NO = N3 > 0 ? N3 : H2;                 // width of dOut
   const TailOff off = tail_off(H1, H2, N3, m.C);
   const TailWs wsl = tail_ws(B, H1, H2, N3, m.C);
+  [[maybe_unused]] const BnOff bo = bn_off(H1, H2);
   float* rec = m.ws + (long)rec_i * off.pv;
   float* dz2g = m.ws + wsl.o_dz2;
   const uint64_t sd1 = m.seed1 + (m.seed_dev ? m.seed_dev[0] : 0), sd2 = m.seed2 + (m.seed_dev ? m.seed_dev[0] : 0);
@@ -433,11 +501,28 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
     g2v[i] = vz[i] ? m.g2[jc[i]] : 0.f;
     zn[i] = xh2[i] * g2v[i] + m.be2[jc[i]];
     kp[i] = vz[i] ? keep_scale(sd2, (uint64_t)rowz * H2 + jc[i], m.p2) : 0.f;
-    a2[i] = leaky_(zn[i], m.slope) * kp[i];
+    if constexpr (BN) a2[i] = (leaky_(zn[i], m.slope) * m.bn_ws[bo.sc2 + jc[i]] + m.bn_ws[bo.sh2 + jc[i]]) * kp[i];
+    else a2[i] = leaky_(zn[i], m.slope) * kp[i];
   }
   float da2[ET_RW];
 #pragma unroll
   for (int i = 0; i < ET_RW; i++) da2[i] = 0.f;
+  f4 da[ET_RW][NCH];
+  f4 xh[ET_RW][NCH];
+  float d2[ET_RW];
+  if (!BN || seg != 3) {
+  if (BN && seg == 2) {
+    // dy2 of the first segment (gradient at the BatchNorm output) -> gradient at the activation output
+    const float invB = 1.f / (float)B;
+#pragma unroll
+    for (int i = 0; i < ET_RW; i++) {
+      const float dy = (vz[i] && livez) ? dz2g[(long)rowz * H2 + jc[i]] : 0.f;
+      const float xb = (leaky_(zn[i], m.slope) - m.bn_ws[bo.mu2 + jc[i]]) * m.bn_ws[bo.rs2 + jc[i]];
+      const float mt = m.bn_train ? (m.bn_ws[bo.s1b + jc[i]] + xb * m.bn_ws[bo.s2b + jc[i]]) * invB : 0.f;
+      da2[i] = vz[i] ? m.bn_ws[bo.sc2 + jc[i]] * (dy - (livez ? mt : 0.f)) : 0.f;
+      kp[i] = vz[i] ? 1.f : 0.f;                   // the dropout mask is already in dy2
+    }
+  } else
   if (N3 > 0) {
     // da2[cell][j] = sum_n dOut[cell][n] W3[n][j];  dW3[n][j] += sum over the wave's cells of dOut[cell][n] a2[cell][j]
 #pragma unroll
@@ -470,8 +555,14 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
 #pragma unroll
     for (int i = 0; i < ET_RW; i++) da2[i] = dor[i];
   }
+  if (BN && seg == 1) {
+#pragma unroll
+    for (int i = 0; i < ET_RW; i++)
+      if (vz[i] && livez) dz2g[(long)rowz * H2 + jc[i]] = da2[i] * kp[i];
+    return;                                       // the column sums of dy2 come next
+  }
   // LayerNorm 2 / activation / dropout backward
-  float dz[ET_RW], dx[ET_RW], d2[ET_RW];
+  float dz[ET_RW], dx[ET_RW];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < ET_RW; i++) {
@@ -503,12 +594,12 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
     }
   }
   // ---- wide part: gradient wrt a1: da[cell][k] = sum_j dz2[cell][j] W2[j][k] ------------------------------------
-  f4 xh[ET_RW][NCH];                              // saved x-hat of layer 1: loaded here, used after the W2 loop
+  if (!BN) {                                      // saved x-hat of layer 1: loaded here, used after the W2 loop
 #pragma unroll
-  for (int r = 0; r < ET_RW; r++)
+    for (int r = 0; r < ET_RW; r++)
 #pragma unroll
-    for (int c = 0; c < NCH; c++) xh[r][c] = *(const f4*)(m.xhat1 + (long)min(row0 + r, B - 1) * H1 + ko[c]);
-  f4 da[ET_RW][NCH];
+      for (int c = 0; c < NCH; c++) xh[r][c] = *(const f4*)(m.xhat1 + (long)min(row0 + r, B - 1) * H1 + ko[c]);
+  }
 #pragma unroll
   for (int r = 0; r < ET_RW; r++)
 #pragma unroll
@@ -548,6 +639,25 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
       }
     }
   }
+  if (BN && seg == 2) {
+    // gradient at the output of BatchNorm 1 (dropout mask applied): handed to the column sums and the last segment
+#pragma unroll
+    for (int r = 0; r < ET_RW; r++) {
+      const int row = min(row0 + r, B - 1);
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+        if (ok[c] && row0 + r < B)
+          *(f4*)(m.bn_dy1 + (long)row * H1 + ko[c]) = da[r][c] * keep4(sd1, (uint64_t)row * H1 + ko[c], m.p1);
+    }
+    return;
+  }
+  }  // seg != 3
+  if (BN && seg == 3) {
+#pragma unroll
+    for (int r = 0; r < ET_RW; r++)
+#pragma unroll
+      for (int c = 0; c < NCH; c++) xh[r][c] = *(const f4*)(m.xhat1 + (long)min(row0 + r, B - 1) * H1 + ko[c]);
+  }
   // LayerNorm 1 / activation / dropout backward; column sums over the wave's cells stay in registers
   f4 sg[NCH], sb[NCH], sd[NCH];
 #pragma unroll
@@ -561,7 +671,21 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
     for (int c = 0; c < NCH; c++) {
       const f4 xl = xh[r][c];
       const f4 z = xl * gam[c] + bet[c];
-      const f4 dzl = dleaky4(z, da[r][c] * keep4(sd1, (uint64_t)row * H1 + ko[c], m.p1), m.slope);
+      f4 gup;                                      // gradient at the activation output
+      if constexpr (BN) {
+        const f4 dy = (row0 + r < B) ? *(const f4*)(m.bn_dy1 + (long)row * H1 + ko[c]) : zero4;
+        const f4 sc = *(const f4*)(m.bn_ws + bo.sc1 + ko[c]);
+        if (m.bn_train) {
+          const f4 xb = (leaky4(z, m.slope) - *(const f4*)(m.bn_ws + bo.mu1 + ko[c])) * *(const f4*)(m.bn_ws + bo.rs1 + ko[c]);
+          const f4 mt = (*(const f4*)(m.bn_ws + bo.s1a + ko[c]) + xb * *(const f4*)(m.bn_ws + bo.s2a + ko[c])) * (1.f / (float)B);
+          gup = (row0 + r < B) ? sc * (dy - mt) : zero4;
+        } else {
+          gup = sc * dy;
+        }
+      } else {
+        gup = da[r][c] * keep4(sd1, (uint64_t)row * H1 + ko[c], m.p1);
+      }
+      const f4 dzl = dleaky4(z, gup, m.slope);
       const f4 dz1 = ok[c] ? dzl : zero4;          // dead cells: dz2 = 0, hence da = 0 and dz1 = 0
       xh[r][c] = ok[c] ? xl : zero4;
       sg[c] += dz1 * xh[r][c];
@@ -635,6 +759,123 @@ __global__ __launch_bounds__(64 * ET_WAVES) void enc_tail_bwd_kernel(TailSet S) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm column kernels.  layer 1: activations a = leaky(xhat1 g1 + be1), [B][H1]; layer 2: the same of the second
+// layer, [B][H2].  A workgroup owns 16 columns; thread (col = tid & 15, rg = tid >> 4) walks rows rg, rg + 16, ...
+// and the 16 partial sums of a column are added in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------
+struct BnLayer {
+  const float *xhat, *g, *be, *w, *b;
+  float *rm, *rv;
+  float eps, mom;
+  int H, sc, sh, mu, rs, s1, s2;
+};
+__device__ __forceinline__ BnLayer bn_layer(const ScpEncTail& m, int layer) {
+  const BnOff o = bn_off(m.H1, m.H2);
+  BnLayer L;
+  if (layer == 1) {
+    L.xhat = m.xhat1; L.g = m.g1; L.be = m.be1; L.w = m.bn1_w; L.b = m.bn1_b; L.rm = m.bn1_rm; L.rv = m.bn1_rv;
+    L.eps = m.bn_eps1; L.mom = m.bn_mom1; L.H = m.H1; L.sc = o.sc1; L.sh = o.sh1; L.mu = o.mu1; L.rs = o.rs1; L.s1 = o.s1a; L.s2 = o.s2a;
+  } else {
+    L.xhat = m.xhat2; L.g = m.g2; L.be = m.be2; L.w = m.bn2_w; L.b = m.bn2_b; L.rm = m.bn2_rm; L.rv = m.bn2_rv;
+    L.eps = m.bn_eps2; L.mom = m.bn_mom2; L.H = m.H2; L.sc = o.sc2; L.sh = o.sh2; L.mu = o.mu2; L.rs = o.rs2; L.s1 = o.s1b; L.s2 = o.s2b;
+  }
+  return L;
+}
+
+// forward: batch mean / biased variance of the activations (two passes, as nn.BatchNorm1d in training mode), running
+// statistics updated in place (unbiased variance), scale = w * rstd and shift = b - mean * scale for the next segment;
+// train = 0: the same vectors from the running statistics.
+__global__ __launch_bounds__(256) void enc_tail_bnstat_kernel(TailSet S, int layer) {
+  __shared__ float red[16][17];
+  const ScpEncTail& m = S.b[blockIdx.y];
+  const BnLayer L = bn_layer(m, layer);
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4, cl = threadIdx.x & 15;
+  if (blockIdx.x * 16 >= L.H) return;              // uniform: a narrower branch of the same launch
+  const int cc = min(col, L.H - 1);
+  const float w = L.w ? L.w[cc] : 1.f, b = L.b ? L.b[cc] : 0.f;
+  float mean, var;
+  if (m.bn_train) {
+    const float g = L.g[cc], be = L.be[cc];
+    float s = 0.f;
+    for (int row = rg; row < m.B; row += 16) s += leaky_(L.xhat[(long)row * L.H + cc] * g + be, m.slope);
+    red[rg][cl] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += red[i][cl];
+    mean = s / (float)m.B;
+    __syncthreads();
+    float q = 0.f;
+    for (int row = rg; row < m.B; row += 16) {
+      const float d = leaky_(L.xhat[(long)row * L.H + cc] * g + be, m.slope) - mean;
+      q += d * d;
+    }
+    red[rg][cl] = q;
+    __syncthreads();
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) q += red[i][cl];
+    var = q / (float)m.B;
+    if (rg == 0 && col < L.H && L.rm && L.rv) {
+      const float unb = m.B > 1 ? var * ((float)m.B / (float)(m.B - 1)) : var;
+      L.rm[col] = (1.f - L.mom) * L.rm[col] + L.mom * mean;
+      L.rv[col] = (1.f - L.mom) * L.rv[col] + L.mom * unb;
+    }
+  } else {
+    mean = L.rm ? L.rm[cc] : 0.f;
+    var = L.rv ? L.rv[cc] : 1.f;
+  }
+  if (rg == 0 && col < L.H) {
+    const float rs = 1.f / sqrtf(var + L.eps);
+    const float sc = w * rs;
+    m.bn_ws[L.sc + col] = sc;
+    m.bn_ws[L.sh + col] = b - mean * sc;
+    m.bn_ws[L.mu + col] = mean;
+    m.bn_ws[L.rs + col] = rs;
+  }
+}
+
+// backward: S1 = sum_cells dy, S2 = sum_cells dy * xhat_bn (xhat_bn = (a - mean) * rstd) of the gradient dy [B][ld] that
+// reaches the BatchNorm output; they are the gradients of the affine bias / weight and the two mean terms of the
+// training-mode input gradient.
+__global__ __launch_bounds__(256) void enc_tail_bnsum_kernel(TailSet S, int layer) {
+  __shared__ float red[2][16][17];
+  const ScpEncTail& m = S.b[blockIdx.y];
+  const BnLayer L = bn_layer(m, layer);
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4, cl = threadIdx.x & 15;
+  if (blockIdx.x * 16 >= L.H) return;              // uniform
+  const int cc = min(col, L.H - 1);
+  const TailWs wsl = tail_ws(m.B, m.H1, m.H2, m.N3, m.C);
+  const float* dy = layer == 1 ? m.bn_dy1 : m.ws + wsl.o_dz2;      // layer 2: the first backward segment left dy2 in the dz2 buffer
+  const float g = L.g[cc], be = L.be[cc], mu = m.bn_ws[L.mu + cc], rs = m.bn_ws[L.rs + cc];
+  float s1 = 0.f, s2 = 0.f;
+  for (int row = rg; row < m.B; row += 16) {
+    const float d = dy[(long)row * L.H + cc];
+    const float xb = (leaky_(L.xhat[(long)row * L.H + cc] * g + be, m.slope) - mu) * rs;
+    s1 += d;
+    s2 += d * xb;
+  }
+  red[0][rg][cl] = s1;
+  red[1][rg][cl] = s2;
+  __syncthreads();
+  if (rg == 0 && col < L.H) {
+    s1 = s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      s1 += red[0][i][cl];
+      s2 += red[1][i][cl];
+    }
+    m.bn_ws[L.s1 + col] = s1;
+    m.bn_ws[L.s2 + col] = s2;
+    float* dw = layer == 1 ? m.dbn1_w : m.dbn2_w;
+    float* db = layer == 1 ? m.dbn1_b : m.dbn2_b;
+    if (dw) dw[col] = s2;
+    if (db) db[col] = s1;
+  }
+}
+
 // dW2 slab of one (128-column block, 64-row chunk): slab[chunk][j][k] = sum over the chunk's rows of dz2[row][j] a1[row][k]
 __global__ __launch_bounds__(256) void enc_tail_w2_kernel(TailSet S) {
   __shared__ float dzs[ETW_ROWS][64];
@@ -655,6 +896,10 @@ __global__ __launch_bounds__(256) void enc_tail_w2_kernel(TailSet S) {
   }
   const int kc = min(k, H1 - 4);
   const f4 gam = *(const f4*)(m.g1 + kc), bet = *(const f4*)(m.be1 + kc);
+  // BatchNorm 1 between activation and dropout (scale 1, shift 0 without it)
+  const BnOff bo = bn_off(H1, H2);
+  const f4 one4 = f4{1.f, 1.f, 1.f, 1.f}, nul4 = f4{0.f, 0.f, 0.f, 0.f};
+  const f4 bsc = m.bn ? *(const f4*)(m.bn_ws + bo.sc1 + kc) : one4, bsh = m.bn ? *(const f4*)(m.bn_ws + bo.sh1 + kc) : nul4;
   __syncthreads();
   for (int pass = 0; pass * 32 < H2; pass++) {
     f4 acc[32];
@@ -670,7 +915,7 @@ __global__ __launch_bounds__(256) void enc_tail_w2_kernel(TailSet S) {
     for (int i = 0; i < ETW_ROWS / 8; i++) {
       const int rr = slot + 8 * i, row = r0 + rr;
       // rows past the batch end have dz2 = 0 in dzs; columns past H1 are never written out
-      const f4 a1 = leaky4(xr[i] * gam + bet, m.slope) * keep4(sd1, (uint64_t)min(row, m.B - 1) * H1 + kc, m.p1);
+      const f4 a1 = (leaky4(xr[i] * gam + bet, m.slope) * bsc + bsh) * keep4(sd1, (uint64_t)min(row, m.B - 1) * H1 + kc, m.p1);
 #pragma unroll
       for (int jj = 0; jj < 32; jj++) acc[jj] += dzs[rr][pass * 32 + jj] * a1;
     }
@@ -781,6 +1026,22 @@ static int tail_check(const ScpEncTail* ms, int nb, const char* who) {
   return SCP_OK;
 }
 
+// BatchNorm encoders: every branch of the call with the same mode, the workspaces present, the hand-over buffers present
+static int tail_check_bn(const ScpEncTail* ms, int nb, const char* who) {
+  for (int b = 0; b < nb; b++) {
+    const ScpEncTail* m = ms + b;
+    SCP_CHECK(m->bn == ms[0].bn && (m->bn_train != 0) == (ms[0].bn_train != 0), SCP_ERR_ARG,
+              "%s: the branches of one call share bn / bn_train", who);
+    SCP_CHECK(m->bn_ws && ((uintptr_t)m->bn_ws & 15) == 0, SCP_ERR_ARG, "%s: BatchNorm needs bn_ws (16-byte aligned)", who);
+    SCP_CHECK(!m->bn_train || (m->xhat1 && m->xhat2 && m->rstd1 && m->rstd2), SCP_ERR_ARG,
+              "%s: batch statistics need the xhat1 / xhat2 / rstd buffers (the segments hand over through them)", who);
+    SCP_CHECK(m->bn_train || ((m->bn1_rm != nullptr) == (m->bn1_rv != nullptr) && (m->bn2_rm != nullptr) == (m->bn2_rv != nullptr)),
+              SCP_ERR_ARG, "%s: running mean and variance go together", who);
+    SCP_CHECK(m->bn_eps1 > 0.f && m->bn_eps2 > 0.f, SCP_ERR_ARG, "%s: BatchNorm eps must be > 0", who);
+  }
+  return SCP_OK;
+}
+
 static int tail_nch(const ScpEncTail* ms, int nb) {
   int h = 0;
   for (int b = 0; b < nb; b++) h = ms[b].H1 > h ? ms[b].H1 : h;
@@ -804,9 +1065,45 @@ extern "C" int scp_enc_tail_fwd(const ScpEncTail* ms, int nbranch, void* stream_
   }
   const int nrec = (ms[0].B + ET_RW - 1) / ET_RW;
   const dim3 grid((nrec + ET_WAVES - 1) / ET_WAVES, nbranch);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (ms[0].bn) {
+    rc = tail_check_bn(ms, nbranch, "scp_enc_tail_fwd");
+    if (rc) return rc;
+    int max_h1 = 0, max_h2 = 0;
+    for (int b = 0; b < nbranch; b++) {
+      max_h1 = ms[b].H1 > max_h1 ? ms[b].H1 : max_h1;
+      max_h2 = ms[b].H2 > max_h2 ? ms[b].H2 : max_h2;
+    }
+    const dim3 gs1((max_h1 + 15) / 16, nbranch), gs2((max_h2 + 15) / 16, nbranch);
+#define ET_FWD_BN(N, SEG)                                                                                     \
+  case N:                                                                                                     \
+    hipLaunchKernelGGL((enc_tail_fwd_kernel<N, true>), grid, dim3(64 * ET_WAVES), 0, stream, S, SEG);          \
+    break;
+#define ET_FWD_SEG(SEG)                                                                                        \
+  switch (tail_nch(ms, nbranch)) { ET_FWD_BN(1, SEG) ET_FWD_BN(2, SEG) ET_FWD_BN(3, SEG) ET_FWD_BN(4, SEG) }  \
+  SCP_LAUNCH_CHECK();
+    if (!ms[0].bn_train) {                         // running statistics: scale / shift of both layers, then one pass
+      hipLaunchKernelGGL(enc_tail_bnstat_kernel, gs1, dim3(256), 0, stream, S, 1);
+      SCP_LAUNCH_CHECK();
+      hipLaunchKernelGGL(enc_tail_bnstat_kernel, gs2, dim3(256), 0, stream, S, 2);
+      SCP_LAUNCH_CHECK();
+      ET_FWD_SEG(0)
+      return SCP_OK;
+    }
+    ET_FWD_SEG(1)
+    hipLaunchKernelGGL(enc_tail_bnstat_kernel, gs1, dim3(256), 0, stream, S, 1);
+    SCP_LAUNCH_CHECK();
+    ET_FWD_SEG(2)
+    hipLaunchKernelGGL(enc_tail_bnstat_kernel, gs2, dim3(256), 0, stream, S, 2);
+    SCP_LAUNCH_CHECK();
+    ET_FWD_SEG(3)
+#undef ET_FWD_SEG
+#undef ET_FWD_BN
+    return SCP_OK;
+  }
 #define ET_FWD(N)                                                                                          \
   case N:                                                                                                  \
-    hipLaunchKernelGGL(enc_tail_fwd_kernel<N>, grid, dim3(64 * ET_WAVES), 0, (hipStream_t)stream_, S);     \
+    hipLaunchKernelGGL((enc_tail_fwd_kernel<N, false>), grid, dim3(64 * ET_WAVES), 0, stream, S, 0);       \
     break;
   switch (tail_nch(ms, nbranch)) { ET_FWD(1) ET_FWD(2) ET_FWD(3) ET_FWD(4) }
 #undef ET_FWD
@@ -815,6 +1112,7 @@ extern "C" int scp_enc_tail_fwd(const ScpEncTail* ms, int nbranch, void* stream_
 }
 
 extern "C" long scp_enc_tail_ws_floats(int B, int H1, int H2, int N3, int C) { return tail_ws(B, H1, H2, N3, C).total; }
+extern "C" long scp_enc_tail_bn_ws_floats(int H1, int H2) { return bn_off(H1, H2).total + 4; }
 
 extern "C" int scp_enc_tail_bwd(const ScpEncTail* ms, int nbranch, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -868,13 +1166,41 @@ extern "C" int scp_enc_tail_bwd(const ScpEncTail* ms, int nbranch, void* stream_
     if (ms[b].dYT && B % 64) {
       SCP_HIP(hipMemsetAsync(ms[b].dYT, 0, (size_t)ms[b].H1 * ms[b].ldt * sizeof(__bf16), stream));
     }
+  if (ms[0].bn) {
+    rc = tail_check_bn(ms, nbranch, "scp_enc_tail_bwd");
+    if (rc) return rc;
+    int max_h2 = 0;
+    for (int b = 0; b < nbranch; b++) {
+      SCP_CHECK(ms[b].bn_dy1 && ((uintptr_t)ms[b].bn_dy1 & 15) == 0, SCP_ERR_ARG,
+                "scp_enc_tail_bwd: BatchNorm needs bn_dy1 [B][H1] (16-byte aligned)");
+      max_h2 = ms[b].H2 > max_h2 ? ms[b].H2 : max_h2;
+    }
+    const dim3 gs1((max_h1 + 15) / 16, nbranch), gs2((max_h2 + 15) / 16, nbranch);
+#define ET_BWD_BN(N, SEG)                                                                                     \
+  case N:                                                                                                     \
+    hipLaunchKernelGGL((enc_tail_bwd_kernel<N, true>), grid, dim3(64 * ET_WAVES), 0, stream, S, SEG);          \
+    break;
+#define ET_BWD_SEG(SEG)                                                                                        \
+  switch (tail_nch(ms, nbranch)) { ET_BWD_BN(1, SEG) ET_BWD_BN(2, SEG) ET_BWD_BN(3, SEG) ET_BWD_BN(4, SEG) }  \
+  SCP_LAUNCH_CHECK();
+    ET_BWD_SEG(1)
+    hipLaunchKernelGGL(enc_tail_bnsum_kernel, gs2, dim3(256), 0, stream, S, 2);
+    SCP_LAUNCH_CHECK();
+    ET_BWD_SEG(2)
+    hipLaunchKernelGGL(enc_tail_bnsum_kernel, gs1, dim3(256), 0, stream, S, 1);
+    SCP_LAUNCH_CHECK();
+    ET_BWD_SEG(3)
+#undef ET_BWD_SEG
+#undef ET_BWD_BN
+  } else {
 #define ET_BWD(N)                                                                              \
   case N:                                                                                      \
-    hipLaunchKernelGGL(enc_tail_bwd_kernel<N>, grid, dim3(64 * ET_WAVES), 0, stream, S);       \
+    hipLaunchKernelGGL((enc_tail_bwd_kernel<N, false>), grid, dim3(64 * ET_WAVES), 0, stream, S, 0);       \
     break;
   switch (tail_nch(ms, nbranch)) { ET_BWD(1) ET_BWD(2) ET_BWD(3) ET_BWD(4) }
 #undef ET_BWD
   SCP_LAUNCH_CHECK();
+  }
   if (any_w2) {
     hipLaunchKernelGGL(enc_tail_w2_kernel, dim3((max_h1 + 127) / 128, nchunk, nbranch), dim3(256), 0, stream, S);
     SCP_LAUNCH_CHECK();

@@ -644,13 +644,17 @@ def _carve(sizes, dev):
 
 class EncBranchesFn(torch.autograd.Function):
     """cfg: dict(slope, br=[dict(p1, p2, seed1, seed2, eps1, eps2, shadow, fused, sink)] per branch);
-    tensors: W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 per branch.  Returns one output per branch."""
+    tensors: W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, bn1_w, bn1_b, bn2_w, bn2_b per branch (the last four: affine
+    parameters of the BatchNorm1d layers of an FCNN built with batchnorm=True, None otherwise; cfg br[i]["bn"] then holds
+    the running tensors, eps, momentum and the mode).  Returns one output per branch."""
+
+    NT = 14
 
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
         L = _lib.lib()
         nb = len(cfg["br"])
-        P = [tensors[10 * i:10 * i + 10] for i in range(nb)]
+        P = [tensors[EncBranchesFn.NT * i:EncBranchesFn.NT * i + EncBranchesFn.NT] for i in range(nb)]
         Bg, F = x.shape                            # rows of the first-layer product
         # feature-sharded data parallelism (distributed.FirstLayerShard): x holds the GLOBAL batch (every rank's slice padded
         # to a common length) restricted to this rank's columns, W1 is this rank's column block; the ranks' partial products
@@ -682,6 +686,11 @@ class EncBranchesFn(torch.autograd.Function):
                   and _rows_adjacent(shadows[0], shadows[1], 2 * shadows[0].shape[1]))
         groups = [list(range(nb))] if merged else [[i] for i in range(nb)]
         train = any(ctx.needs_input_grad)
+        bns = [b_.get("bn") for b_ in cfg["br"]]
+        has_bn = bns[0] is not None
+        if any((b_ is not None) != has_bn or (has_bn and b_["train"] != bns[0]["train"]) for b_ in bns):
+            raise ValueError("encoder: the branches of one call share the BatchNorm mode")
+        keep_saves = train or (has_bn and bns[0]["train"])      # batch statistics: the segments hand over through them
         nouts = [n3 if n3 > 0 else h2 for n3, h2 in zip(N3s, H2s)]
         # one allocation: slabs of every first-layer launch | outputs | saved-for-backward pieces
         nsplits, slab_sizes = [], []
@@ -696,13 +705,17 @@ class EncBranchesFn(torch.autograd.Function):
             nsplits.append(nsp)
             slab_sizes.append(nsp * Bg * Hg)
         sizes = list(slab_sizes) + [Bn * n for n in nouts]
-        if train:
+        if keep_saves:
             for i in range(nb):
                 sizes += [Bn * H1s[i], Bn, Bn * H2s[i], Bn]
+        n_before_bn = len(sizes)
+        if has_bn:
+            sizes += [L.scp_enc_tail_bn_ws_floats(H1s[i], H2s[i]) for i in range(nb)]
         buf, pieces = _carve(sizes, dev)
         slabs = pieces[:len(groups)]
         outs = [pieces[len(groups) + i].view(Bn, nouts[i]) for i in range(nb)]
-        saves = [pieces[len(groups) + nb + 4 * i:len(groups) + nb + 4 * i + 4] if train else (None,) * 4 for i in range(nb)]
+        saves = [pieces[len(groups) + nb + 4 * i:len(groups) + nb + 4 * i + 4] if keep_saves else (None,) * 4 for i in range(nb)]
+        bn_wss = pieces[n_before_bn:n_before_bn + nb] if has_bn else [None] * nb
         stream = _lib.stream()
         slab_of = {}
         shd_keep = []
@@ -737,10 +750,18 @@ class EncBranchesFn(torch.autograd.Function):
         seed_dev = _seed_dev() if any_drop else None
         arr = (_lib.EncTail * nb)()
         for i in range(nb):
-            W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 = P[i]
+            W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, bn1w, bn1b, bn2w, bn2b = P[i]
             c = cfg["br"][i]
             m = arr[i]
             m.B, m.H1, m.H2, m.N3 = Bn, H1s[i], H2s[i], N3s[i]
+            if has_bn:
+                bn = bns[i]
+                m.bn, m.bn_train = 1, int(bn["train"])
+                m.bn1_w, m.bn1_b, m.bn2_w, m.bn2_b = _lib.ptr(bn1w), _lib.ptr(bn1b), _lib.ptr(bn2w), _lib.ptr(bn2b)
+                m.bn1_rm, m.bn1_rv, m.bn2_rm, m.bn2_rv = (_lib.ptr(bn["rm1"]), _lib.ptr(bn["rv1"]), _lib.ptr(bn["rm2"]),
+                                                          _lib.ptr(bn["rv2"]))
+                m.bn_eps1, m.bn_eps2, m.bn_mom1, m.bn_mom2 = bn["eps1"], bn["eps2"], bn["mom1"], bn["mom2"]
+                m.bn_ws = bn_wss[i].data_ptr()
             m.b1, m.g1, m.be1 = _lib.ptr(b1), g1.data_ptr(), be1.data_ptr()
             m.W2, m.b2, m.g2, m.be2 = W2.data_ptr(), b2.data_ptr(), g2.data_ptr(), be2.data_ptr()
             m.W3, m.b3 = _lib.ptr(W3), _lib.ptr(b3)
@@ -771,7 +792,7 @@ class EncBranchesFn(torch.autograd.Function):
         Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn, ldws = ctx.dims
         Ft = F + Cn
         nb = len(H1s)
-        P = [tensors[10 * i:10 * i + 10] for i in range(nb)]
+        P = [tensors[EncBranchesFn.NT * i:EncBranchesFn.NT * i + EncBranchesFn.NT] for i in range(nb)]
         cfg, arr, t = ctx.cfg, ctx.arr, ctx.tiles
         dev = P[0][0].device
         stream = _lib.stream()
@@ -779,13 +800,15 @@ class EncBranchesFn(torch.autograd.Function):
         Bg = Bn if shd is None else shd.world * shd.width      # rows of the first-layer weight-gradient product
         ldt = (Bn + 63) // 64 * 64 if shd is None else shd.width
         # one allocation for every small gradient and the workspaces; the first-layer gradient operand separately
+        has_bn = cfg["br"][0].get("bn") is not None
         sizes = []
         for i in range(nb):
             nws = L.scp_enc_tail_ws_floats(Bn, H1s[i], H2s[i], N3s[i], Cn)
             sizes += [H1s[i], H1s[i], H1s[i], H2s[i], H2s[i], H2s[i], N3s[i] * H2s[i], N3s[i], H2s[i] * H1s[i], nws,
                       0 if use_bf else Bn * H1s[i]]
+            sizes += [H1s[i], H1s[i], H2s[i], H2s[i], Bn * H1s[i]] if has_bn else [0, 0, 0, 0, 0]
         gb, pieces = _carve(sizes, dev)
-        need_w1 = [ctx.needs_input_grad[2 + 10 * i] for i in range(nb)]
+        need_w1 = [ctx.needs_input_grad[2 + EncBranchesFn.NT * i] for i in range(nb)]
         dYT = {}
         if use_bf:
             for g in groups:
@@ -838,7 +861,7 @@ class EncBranchesFn(torch.autograd.Function):
         keep = []
         grads = []
         for i in range(nb):
-            dg1, dbe1, db1, dg2, dbe2, db2, dW3, db3, dW2, ws, dY1 = pieces[11 * i:11 * i + 11]
+            dg1, dbe1, db1, dg2, dbe2, db2, dW3, db3, dW2, ws, dY1, dbn1w, dbn1b, dbn2w, dbn2b, bn_dy1 = pieces[16 * i:16 * i + 16]
             W1, b1 = P[i][0], P[i][1]
             nout = N3s[i] if N3s[i] else H2s[i]
             do = douts[i]
@@ -860,8 +883,15 @@ class EncBranchesFn(torch.autograd.Function):
             m.dW2, m.dg2, m.dbe2, m.db2 = dW2.data_ptr(), dg2.data_ptr(), dbe2.data_ptr(), db2.data_ptr()
             m.dW3, m.db3 = _lib.ptr(dW3 if N3s[i] else None), _lib.ptr(db3 if N3s[i] else None)
             m.dW1c, m.lddw1c, m.adam = None, 0, 0
+            gbn = [None] * 4
+            if has_bn:
+                m.bn_dy1 = bn_dy1.data_ptr()
+                has_aff = [P[i][10 + k] is not None for k in range(4)]
+                m.dbn1_w, m.dbn1_b = _lib.ptr(dbn1w if has_aff[0] else None), _lib.ptr(dbn1b if has_aff[1] else None)
+                m.dbn2_w, m.dbn2_b = _lib.ptr(dbn2w if has_aff[2] else None), _lib.ptr(dbn2b if has_aff[3] else None)
+                gbn = [t_ if ok_ else None for t_, ok_ in zip((dbn1w, dbn1b, dbn2w, dbn2b), has_aff)]
             grads.append([None, db1 if b1 is not None else None, dg1, dbe1, dW2.view(H2s[i], H1s[i]), db2, dg2, dbe2,
-                          dW3.view(N3s[i], H2s[i]) if N3s[i] else None, db3 if N3s[i] else None])
+                          dW3.view(N3s[i], H2s[i]) if N3s[i] else None, db3 if N3s[i] else None] + gbn)
         if Cn:
             # the covariate columns of each branch's first-layer gradient (or their AdamW step) come out of the tail
             for u, mode, payload in plan:
@@ -978,7 +1008,8 @@ def _fused_pair_ok(fa, fb, Wa, Wb):
 
 def enc_branches(x, branches, slope, seeds=None, cov=None):
     """branches: list of dicts with W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 (W3 / b3 / b1 may be None) and optional
-    p1, p2, eps1, eps2.  seeds: optional list of (seed1, seed2) per branch (tests); drawn from next_seed() otherwise.
+    p1, p2, eps1, eps2; for an FCNN built with batchnorm=True additionally bn1_w, bn1_b, bn2_w, bn2_b (affine parameters or
+    None) and bn = dict(rm1, rv1, rm2, rv2: running tensors or None, eps1, eps2, mom1, mom2, train) (see bn_spec()).  seeds: optional list of (seed1, seed2) per branch (tests); drawn from next_seed() otherwise.
     cov: optional [B, C] covariate block the reference concatenates to the input (model.py:128); W1 is then [H1, F + C].
     Returns the list of branch outputs."""
     if not 1 <= len(branches) <= ENC_MAX_BRANCHES:
@@ -1000,9 +1031,27 @@ def enc_branches(x, branches, slope, seeds=None, cov=None):
         else:
             s1, s2 = (next_seed() if p1 > 0 else 0), (next_seed() if p2 > 0 else 0)
         cfg["br"].append(dict(p1=p1, p2=p2, seed1=int(s1), seed2=int(s2), eps1=float(b.get("eps1", 1e-5)),
-                              eps2=float(b.get("eps2", 1e-5)), shadow=shadow, fused=fused, sink=sink))
-        tensors += [W1, b.get("b1"), b["g1"], b["be1"], b["W2"], b["b2"], b["g2"], b["be2"], b.get("W3"), b.get("b3")]
+                              eps2=float(b.get("eps2", 1e-5)), shadow=shadow, fused=fused, sink=sink, bn=b.get("bn")))
+        tensors += [W1, b.get("b1"), b["g1"], b["be1"], b["W2"], b["b2"], b["g2"], b["be2"], b.get("W3"), b.get("b3"),
+                    b.get("bn1_w"), b.get("bn1_b"), b.get("bn2_w"), b.get("bn2_b")]
     return list(EncBranchesFn.apply(x, cfg, *tensors))
+
+
+def bn_spec(bn1, bn2, training):
+    """The `bn` entry of an enc_branches() branch for two nn.BatchNorm1d modules, with nn.BatchNorm1d's bookkeeping:
+    num_batches_tracked advances in training mode, momentum None means the cumulative moving average."""
+    out = {"train": bool(training) or bn1.running_mean is None or bn2.running_mean is None}
+    for k, bn in (("1", bn1), ("2", bn2)):
+        if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        mom = bn.momentum
+        if mom is None:
+            mom = 1.0 / float(bn.num_batches_tracked) if (training and bn.num_batches_tracked is not None) else 0.0
+        track = bn.track_running_stats and bn.running_mean is not None
+        out["rm" + k] = bn.running_mean if track else None
+        out["rv" + k] = bn.running_var if track else None
+        out["eps" + k], out["mom" + k] = float(bn.eps), float(mom)
+    return out
 
 
 def enc_branch(x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, slope, p1=0.0, p2=0.0, eps1=1e-5, eps2=1e-5, seeds=None):

@@ -82,8 +82,9 @@ class HipFCNN(nn.Sequential):
 
 def _branch_spec(fcnn, final, x, cov):
     """The tensors of an encoder branch the fused path (ops.enc_branches) takes, or None when the branch has another
-    shape than the reference's default (sparse minibatch, optionally a covariate block, two FCNN layers with LayerNorm
-    and no BatchNorm, a Linear with bias behind them or none)."""
+    shape than the reference's default (sparse minibatch, optionally a covariate block, two FCNN layers with LayerNorm,
+    both with or both without BatchNorm1d, a Linear with bias behind them or none).  BatchNorm encoders under data
+    parallelism keep the layer-by-layer path: their global-batch statistics live in ops.SyncBatchNormFn."""
     groups = fcnn._groups() if isinstance(fcnn, HipFCNN) else None
     if groups is None or len(groups) != 2:
         return None
@@ -94,14 +95,19 @@ def _branch_spec(fcnn, final, x, cov):
         same_act = _slope_of(a2) == slope
     except NotImplementedError:
         return None
-    if not (same_act and bn1 is None and bn2 is None and (final is None or final.bias is not None) and l2.bias is not None
+    if (bn1 is None) != (bn2 is None) or (bn1 is not None and (ops.bn_sync_active() or getattr(x, "shard", None) is not None)):
+        return None
+    if not (same_act and (final is None or final.bias is not None) and l2.bias is not None
             and ops.enc_branch_supported(x, cov, l1.weight, l2.weight, W3, n1 is not None, n2 is not None)
             and n1.elementwise_affine and n2.elementwise_affine):
         return None
     return dict(W1=l1.weight, b1=l1.bias, g1=n1.weight, be1=n1.bias, W2=l2.weight, b2=l2.bias, g2=n2.weight, be2=n2.bias,
                 W3=W3, b3=None if final is None else final.bias, eps1=n1.eps, eps2=n2.eps, slope=slope,
                 p1=float(d1.p) if (fcnn.training and d1.p > 0) else 0.0,
-                p2=float(d2.p) if (fcnn.training and d2.p > 0) else 0.0)
+                p2=float(d2.p) if (fcnn.training and d2.p > 0) else 0.0,
+                bn_mods=None if bn1 is None else (bn1, bn2, fcnn.training),
+                bn1_w=None if bn1 is None else bn1.weight, bn1_b=None if bn1 is None else bn1.bias,
+                bn2_w=None if bn2 is None else bn2.weight, bn2_b=None if bn2 is None else bn2.bias)
 
 
 def encoder_branches(branches, x, cov=None):
@@ -119,9 +125,15 @@ def encoder_branches(branches, x, cov=None):
     fusable = [i for i, sp in enumerate(specs) if sp is not None]
     by_slope = {}
     for i in fusable:
-        by_slope.setdefault(specs[i]["slope"], []).append(i)
-    for slope, idx in by_slope.items():
+        # one call = one slope and one BatchNorm mode (none / batch statistics / running statistics)
+        bm = specs[i]["bn_mods"]
+        mode = None if bm is None else bool(bm[2] or bm[0].running_mean is None or bm[1].running_mean is None)
+        by_slope.setdefault((specs[i]["slope"], mode), []).append(i)
+    for (slope, _mode), idx in by_slope.items():
         idx = idx[:ops.ENC_MAX_BRANCHES]
+        for i in idx:
+            bm = specs[i]["bn_mods"]
+            specs[i]["bn"] = None if bm is None else ops.bn_spec(*bm)      # nn.BatchNorm1d's bookkeeping: once per forward
         res = ops.enc_branches(x, [specs[i] for i in idx], slope, cov=cov)
         for i, r in zip(idx, res):
             outs[i] = r

@@ -384,3 +384,85 @@ def test_homed_first_layers_any_feature_count(F, C):
                 assert torch.allclose(a[k], b[k], rtol=2e-5, atol=2e-6), (k, float((a[k] - b[k]).abs().max()))
     finally:
         S.set_precision("fp32")
+
+
+def _ref_bn(P, BN, x, rnd, training, cov=None):
+    """fp64 forward of an FCNN built with batchnorm=True (utils.py:54-64: Linear -> LayerNorm -> LeakyReLU -> BatchNorm1d
+    -> Dropout per layer) + the Linear behind it; BN: dict with w1, b1, rm1, rv1, w2, b2, rm2, rv2 (fp32 tensors), eps,
+    momentum.  Returns the leaf dict, the output and the updated running statistics."""
+    q = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    qb = {k: BN[k].double().requires_grad_(True) for k in ("w1", "b1", "w2", "b2")}
+    F = x.shape[1]
+    W1 = q["W1"][:, :F] + (rnd(P["W1"][:, :F]) - P["W1"][:, :F].double()).detach()
+    y = rnd(x) @ W1.t() + q["b1"]
+    if cov is not None:
+        y = y + cov.double() @ q["W1"][:, F:].t()
+    run = {}
+
+    def bn(a, k):
+        rm, rv = BN["rm" + k].double().clone(), BN["rv" + k].double().clone()
+        o = Fn.batch_norm(a, rm, rv, qb["w" + k], qb["b" + k], training, BN["momentum"], BN["eps"])
+        run["rm" + k], run["rv" + k] = rm, rv
+        return o
+    a1 = bn(Fn.leaky_relu(Fn.layer_norm(y, (y.shape[1],), q["g1"], q["be1"]), 0.01), "1")
+    z2 = Fn.layer_norm(a1 @ q["W2"].t() + q["b2"], (q["W2"].shape[0],), q["g2"], q["be2"])
+    a2 = bn(Fn.leaky_relu(z2, 0.01), "2")
+    out = a2 @ q["W3"].t() + q["b3"] if "W3" in q else a2
+    q.update({"bn" + k: v for k, v in qb.items()})
+    return q, out, run
+
+
+@pytest.mark.parametrize("B,F,H1,H2,N3,C", [(1024, 2000, 900, 40, 40, 0), (257, 700, 800, 30, 1, 4), (130, 333, 16, 8, 0, 0),
+                                            (67, 515, 1024, 64, 64, 3)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_encoder_branch_with_batchnorm(B, F, H1, H2, N3, C, prec):
+    """batchnorm=True encoders (the tutorial's configuration) on the fused tail: three forward segments with the
+    column-statistics kernel between them, three backward segments with the column-sum kernel between them.  Training
+    mode (batch statistics, running statistics updated in place with the unbiased variance) and eval mode (running
+    statistics), output and the gradient of every parameter incl. the BatchNorm affine ones, against fp64."""
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision(prec)
+    try:
+        rng = np.random.default_rng(B + F + 1)
+        m = _csr(rng, B + 11, F, 0.06)
+        rows = rng.permutation(B + 11)[:B]
+        x = torch.tensor(np.asarray(m[rows].todense(), dtype=np.float32))
+        rnd = (lambda t: t.bfloat16().double()) if prec == "bf16" else (lambda t: t.double())
+        g = torch.Generator().manual_seed(H1 + N3 + 5)
+        P = _params(g, F + C, H1, H2, N3)
+        cov = torch.randn(B, C, generator=g) if C else None
+        BN = dict(w1=1 + 0.2 * torch.randn(H1, generator=g), b1=0.1 * torch.randn(H1, generator=g),
+                  rm1=0.1 * torch.randn(H1, generator=g), rv1=0.5 + torch.rand(H1, generator=g),
+                  w2=1 + 0.2 * torch.randn(H2, generator=g), b2=0.1 * torch.randn(H2, generator=g),
+                  rm2=0.1 * torch.randn(H2, generator=g), rv2=0.5 + torch.rand(H2, generator=g), eps=1e-5, momentum=0.1)
+        wout = torch.randn(B, N3 if N3 else H2, generator=g)
+        tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), rows)
+        covd = None if cov is None else cov.to(DEV)
+        for training in (True, False):
+            q, out_r, run = _ref_bn(P, BN, x, rnd, training, cov)
+            (out_r * wout.double()).sum().backward()
+            d = {k: v.clone().to(DEV).requires_grad_(True) for k, v in P.items()}
+            db = {k: BN[k].clone().to(DEV).requires_grad_(True) for k in ("w1", "b1", "w2", "b2")}
+            rs = {k: BN[k].clone().to(DEV) for k in ("rm1", "rv1", "rm2", "rv2")}
+            spec = dict(W1=d["W1"], b1=d["b1"], g1=d["g1"], be1=d["be1"], W2=d["W2"], b2=d["b2"], g2=d["g2"], be2=d["be2"],
+                        W3=d.get("W3"), b3=d.get("b3"), bn1_w=db["w1"], bn1_b=db["b1"], bn2_w=db["w2"], bn2_b=db["b2"],
+                        bn=dict(train=training, rm1=rs["rm1"], rv1=rs["rv1"], rm2=rs["rm2"], rv2=rs["rv2"], eps1=1e-5, eps2=1e-5,
+                                mom1=0.1, mom2=0.1))
+            out = ops.enc_branches(tiles, [spec], 0.01, cov=covd)[0]
+            (out * wout.to(DEV)).sum().backward()
+            rt = 2e-4 if prec == "fp32" else 2e-3
+            _check(f"out train={training}", out, out_r, rt)
+            for k in P:
+                assert d[k].grad is not None, k
+                _check(f"{k} train={training}", d[k].grad, q[k].grad, rt * (10 if (k == "W1" and prec == "bf16") else 1))
+            for k in db:
+                _check(f"bn {k} train={training}", db[k].grad, q["bn" + k].grad, rt)
+            for k in rs:                                # running statistics: updated in training mode, untouched in eval mode
+                _check(f"{k} train={training}", rs[k], run[k], 1e-5 if prec == "fp32" else 2e-3)
+            if not training:
+                with torch.no_grad():
+                    out_e = ops.enc_branches(tiles, [spec], 0.01, cov=covd)[0]
+                assert torch.equal(out_e, out.detach())
+    finally:
+        S.set_precision("fp32")
