@@ -386,7 +386,7 @@ def test_homed_first_layers_any_feature_count(F, C):
         S.set_precision("fp32")
 
 
-def _ref_bn(P, BN, x, rnd, training, cov=None):
+def _ref_bn(P, BN, x, rnd, training, cov=None, keep1=None, keep2=None):
     """fp64 forward of an FCNN built with batchnorm=True (utils.py:54-64: Linear -> LayerNorm -> LeakyReLU -> BatchNorm1d
     -> Dropout per layer) + the Linear behind it; BN: dict with w1, b1, rm1, rv1, w2, b2, rm2, rv2 (fp32 tensors), eps,
     momentum.  Returns the leaf dict, the output and the updated running statistics."""
@@ -405,8 +405,12 @@ def _ref_bn(P, BN, x, rnd, training, cov=None):
         run["rm" + k], run["rv" + k] = rm, rv
         return o
     a1 = bn(Fn.leaky_relu(Fn.layer_norm(y, (y.shape[1],), q["g1"], q["be1"]), 0.01), "1")
+    if keep1 is not None:
+        a1 = a1 * keep1
     z2 = Fn.layer_norm(a1 @ q["W2"].t() + q["b2"], (q["W2"].shape[0],), q["g2"], q["be2"])
     a2 = bn(Fn.leaky_relu(z2, 0.01), "2")
+    if keep2 is not None:
+        a2 = a2 * keep2
     out = a2 @ q["W3"].t() + q["b3"] if "W3" in q else a2
     q.update({"bn" + k: v for k, v in qb.items()})
     return q, out, run
@@ -466,3 +470,49 @@ def test_encoder_branch_with_batchnorm(B, F, H1, H2, N3, C, prec):
                 assert torch.equal(out_e, out.detach())
     finally:
         S.set_precision("fp32")
+
+
+def test_two_batchnorm_branches_with_dropout():
+    """Two BatchNorm branches of one encoder in one call (hidden_rep + extra Linear, hidden_lib + library head), dropout
+    behind each BatchNorm: forward and every gradient against fp64 with the very masks the kernels draw."""
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision("fp32")
+    B, F, H2 = 203, 400, 16
+    rng = np.random.default_rng(3)
+    m = _csr(rng, B, F, 0.1)
+    x = torch.tensor(np.asarray(m.todense(), dtype=np.float32))
+    tiles = S.BatchTiles(S.DeviceCSR.from_scipy(m, DEV), np.arange(B))
+    g = torch.Generator().manual_seed(11)
+    specs, refs, wouts, leaves = [], [], [], []
+    for bi, (H1, N3, p1, p2) in enumerate([(132, 5, 0.3, 0.2), (64, 1, 0.25, 0.0)]):
+        seeds = (100 + bi, 200 + bi)
+        keep1 = _mask(ops, seeds[0], B, H1, p1)
+        keep2 = _mask(ops, seeds[1], B, H2, p2) if p2 > 0 else None
+        P = _params(g, F, H1, H2, N3)
+        BN = dict(w1=1 + 0.2 * torch.randn(H1, generator=g), b1=0.1 * torch.randn(H1, generator=g), rm1=torch.zeros(H1),
+                  rv1=torch.ones(H1), w2=1 + 0.2 * torch.randn(H2, generator=g), b2=0.1 * torch.randn(H2, generator=g),
+                  rm2=torch.zeros(H2), rv2=torch.ones(H2), eps=1e-5, momentum=0.1)
+        q, out_r, run = _ref_bn(P, BN, x, lambda t: t.double(), True, None, keep1, keep2)
+        wout = torch.randn(B, N3, generator=g)
+        (out_r * wout.double()).sum().backward()
+        d = {k: v.clone().to(DEV).requires_grad_(True) for k, v in P.items()}
+        db = {k: BN[k].clone().to(DEV).requires_grad_(True) for k in ("w1", "b1", "w2", "b2")}
+        rs = {k: BN[k].clone().to(DEV) for k in ("rm1", "rv1", "rm2", "rv2")}
+        specs.append(dict(W1=d["W1"], b1=d["b1"], g1=d["g1"], be1=d["be1"], W2=d["W2"], b2=d["b2"], g2=d["g2"], be2=d["be2"],
+                          W3=d["W3"], b3=d["b3"], p1=p1, p2=p2, bn1_w=db["w1"], bn1_b=db["b1"], bn2_w=db["w2"], bn2_b=db["b2"],
+                          bn=dict(train=True, rm1=rs["rm1"], rv1=rs["rv1"], rm2=rs["rm2"], rv2=rs["rv2"], eps1=1e-5, eps2=1e-5,
+                                  mom1=0.1, mom2=0.1)))
+        refs.append((q, out_r, run, P, d, db, rs))
+        wouts.append(wout)
+        leaves.append(seeds)
+    outs = ops.enc_branches(tiles, specs, 0.01, seeds=leaves)
+    sum((o * w.to(DEV)).sum() for o, w in zip(outs, wouts)).backward()
+    for bi, (q, out_r, run, P, d, db, rs) in enumerate(refs):
+        _check(f"out{bi}", outs[bi], out_r, 2e-4)
+        for k in P:
+            _check(f"{k}{bi}", d[k].grad, q[k].grad, 2e-4)
+        for k in db:
+            _check(f"bn {k}{bi}", db[k].grad, q["bn" + k].grad, 2e-4)
+        for k in rs:
+            _check(f"{k}{bi}", rs[k], run[k], 1e-5)
