@@ -149,6 +149,8 @@ class Output_Module_Ber(nn.Module):
     def fused_loss(self, latent_rep, output_batch, lib, latent_lib, labels, likelihood="ber"):
         """binarized_loss(labels, forward(...)[0]) in one kernel pass with its backward (no [cells x peaks] tensor)."""
         h = _cat_cov(latent_rep, output_batch)
+        if not ops.decoder_depth_supported(h.shape[1]):
+            return None                                # many covariate levels: materialised forward + dense BCE kernel
         fs = self.feature_scalar if self.feature_factor == True else None  # noqa: E712
         return ops.ber_decoder_loss(h, self.output_layer.weight, self.output_layer.bias, fs,
                                     self._lrow(lib, latent_lib), labels)
@@ -257,6 +259,8 @@ class Output_Module_Raw(nn.Module):
         else:
             raise Exception("The library size is missing. Please ensure that either the 'sample_factor' or "
                             "'infer_library_size' parameter for the raw counts decoder is set to True.")
+        if not ops.decoder_depth_supported(h.shape[1]):
+            return None                                # many covariate levels: materialised forward + dense NB kernels
         return ops.nb_decoder_loss(h, lin.weight, lin.bias, fs, thp, L, lat, labels)
 
 

@@ -1303,6 +1303,13 @@ class BerDecoderLossFn(torch.autograd.Function):
         return dh, dW, db, dfs, dl_, None
 
 
+def decoder_depth_supported(K: int) -> bool:
+    """The fused decoders (scp_ber_dec_bce, scp_nb_dec_ll) hold the whole contraction depth K = latent width + one-hot
+    covariate columns in registers / LDS: K <= 64 with bf16 MFMA inputs, K <= 48 in the fp32-equivalent mode.  Deeper
+    decoders (many covariate levels) take the materialised forward + the dense likelihood kernels instead."""
+    return int(K) <= (64 if _ns() == 1 else 48)
+
+
 def ber_decoder_loss(h, W, b, fs, lrow, tiles):
     return BerDecoderLossFn.apply(h, W, b, fs, lrow, tiles)
 

@@ -936,3 +936,57 @@ def test_first_layer_wgrad_tail_rows(S, B, F, H, binary):
         assert torch.equal(g1, g2)
     finally:
         ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_decoders_with_many_covariate_levels_take_the_materialised_path(S, prec):
+    """Contraction depth K = latent width + one-hot covariate columns beyond what the fused decoders hold (64 with bf16
+    MFMA inputs, 48 in the fp32-equivalent mode): Output_Module_Ber / Output_Module_Raw.fused_loss() decline and the
+    step goes through the materialised forward + the dense likelihood kernels, against the CPU oracle."""
+    O = S.O
+    import scpair_amd as A
+    S.ops.set_precision(prec)
+    try:
+        B, F, lat_w, C = 70, 300, 40, 60                       # K = 100
+        rng = np.random.default_rng(4)
+        g = torch.Generator().manual_seed(4)
+        z = torch.randn(B, lat_w, generator=g) * 0.5
+        cov = torch.nn.functional.one_hot(torch.randint(0, C, (B,), generator=g), C).float()
+        assert not S.ops.decoder_depth_supported(lat_w + C) and S.ops.decoder_depth_supported(40)
+        tol = 2e-5 if prec == "fp32" else 2e-2
+        # Bernoulli
+        dec = A.Output_Module_Ber(F, C, [900, lat_w], infer_library_size=False, sample_factor=False, feature_factor=False).to(S.dev)
+        yb = rand_csr(rng, B, F, 0.05, binary=True)
+        ybd = torch.tensor(np.asarray(yb.todense(), dtype=np.float32))
+        tiles = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(yb, S.dev, binary=True), np.arange(B))
+        zd = z.clone().to(S.dev).requires_grad_(True)
+        assert dec.fused_loss(zd, cov.to(S.dev), None, None, tiles, "ber") is None
+        enc = lambda x, c: (zd, None)
+        loss = A.utils._predictor_loss(None, tiles, None, enc, dec, "ber", True, None, cov.to(S.dev))
+        loss.backward()
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+        zr = z.clone().requires_grad_(True)
+        res = O.output_ber(sd, zr, cov, None, None, sample_factor=False)
+        lo = O.bce_masked(ybd, res[0]); lo.backward()
+        close(loss, lo, rtol=tol, atol=0, what="ber loss, K = 100")
+        close(zd.grad, zr.grad, rtol=10 * tol, atol=10 * tol * float(zr.grad.abs().max()), what="ber dz")
+        close(dec.output_layer.weight.grad, sd["output_layer.weight"].grad, rtol=10 * tol,
+              atol=10 * tol * float(sd["output_layer.weight"].grad.abs().max()), what="ber dW")
+        # NB with the observed library size
+        decn = A.Output_Module_Raw(F, C, [900, lat_w], infer_library_size=False, sample_factor=True, zero_inflated=False,
+                                   dispersion="feature").to(S.dev)
+        yn = rand_csr(rng, B, F, 0.1)
+        ynd = torch.tensor(np.asarray(yn.todense(), dtype=np.float32))
+        tn = S.sparse.BatchTiles(S.sparse.DeviceCSR.from_scipy(yn, S.dev), np.arange(B))
+        zd = z.clone().to(S.dev).requires_grad_(True)
+        assert decn.fused_loss(zd, cov.to(S.dev), tn.lib.reshape(-1, 1), None, tn, "nb") is None
+        loss = A.utils._predictor_loss(None, tn, tn.lib.reshape(-1, 1), enc, decn, "nb", True, None, cov.to(S.dev))
+        loss.backward()
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in decn.state_dict().items()}
+        zr = z.clone().requires_grad_(True)
+        scale, theta, rate, _ = O.output_raw(sd, zr, cov, ynd.sum(1, keepdim=True), None, True, dispersion="feature")
+        lo = O.raw_loss(ynd, rate, theta, None, "nb"); lo.backward()
+        close(loss, lo, rtol=max(tol, 5e-5), atol=0, what="nb loss, K = 100")
+        close(zd.grad, zr.grad, rtol=10 * tol, atol=10 * tol * float(zr.grad.abs().max()), what="nb dz")
+    finally:
+        S.ops.set_precision("fp32")
