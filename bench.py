@@ -536,6 +536,8 @@ def main():
     prof = None
     if os.environ.get("SCPAIR_BENCH_CPROFILE") and rank == 0:      # diagnostic: where the host enqueue time goes
         import cProfile
+        # the Python backward functions run on autograd's worker thread, which cProfile does not see: run them here
+        torch.autograd.set_multithreading_enabled(False)
         prof = cProfile.Profile()
         prof.enable()
     for k_ in host_t:
