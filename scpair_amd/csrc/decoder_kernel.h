@@ -28,7 +28,12 @@
 #define FT 64        // features per tile
 #define LDZ 72       // padded leading dim of the 64-wide bf16 images
 
-enum { MODE_BER_TRAIN = 0, MODE_BER_EVAL = 1, MODE_NB_STATS = 2, MODE_NB_LOSS = 3, MODE_NB_GRAD = 4 };
+// _TH: the NB likelihood / gradient passes with dispersion = 'feature' (theta_param given).  The default, dispersion
+// 'feature-cell' (theta = exp(relu(z)) >= 1), is its own instantiation: theta + eps == theta in fp32 (eps = 1e-8 is below
+// half an ulp of 1), so log(theta + eps) is relu(z) itself and theta / (theta + eps) is 1 -- one logarithm (and in the
+// gradient pass one reciprocal) per element less, and no run-time selects on the dispersion kind.
+enum { MODE_BER_TRAIN = 0, MODE_BER_EVAL = 1, MODE_NB_STATS = 2, MODE_NB_LOSS = 3, MODE_NB_GRAD = 4, MODE_NB_LOSS_TH = 5,
+       MODE_NB_GRAD_TH = 6 };
 
 struct DecArgs {
   int B, F, K;                 // cells, output features, contraction depth (latent + covariates)
@@ -97,7 +102,10 @@ __device__ __forceinline__ bf16x8 dec_read_tr(const __bf16* img, int k0, int m0,
 template <int NS, int KP, int NPT, int MODE, bool VEC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dec_kernel(DecArgs g) {
   constexpr bool IS_BER = (MODE == MODE_BER_TRAIN || MODE == MODE_BER_EVAL);
-  constexpr bool TRAIN = (MODE == MODE_BER_TRAIN || MODE == MODE_NB_GRAD);
+  constexpr bool NB_LOSS = (MODE == MODE_NB_LOSS || MODE == MODE_NB_LOSS_TH);
+  constexpr bool NB_GRAD = (MODE == MODE_NB_GRAD || MODE == MODE_NB_GRAD_TH);
+  constexpr bool THP = (MODE == MODE_NB_LOSS_TH || MODE == MODE_NB_GRAD_TH);       // dispersion = 'feature'
+  constexpr bool TRAIN = (MODE == MODE_BER_TRAIN || NB_GRAD);
   constexpr bool NEED_LABELS = (MODE != MODE_NB_STATS);
   constexpr int LDK_ = KP + 8;
   constexpr int NTK = (KP + 31) / 32;      // 32-wide column tiles covering K
@@ -190,14 +198,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     const int fc = min(f0n + (wave & 1) * 32 + (lane & 31), g.F - 1);
     bias_n = g.bias[fc];
     if (g.fs) fs_n = g.fs[fc];
-    if (!IS_BER && g.theta_param) th_n = g.theta_param[fc];
+    if (THP) th_n = g.theta_param[fc];
   };
   auto load_h = [&](int c0n) {
     load_rows(hreg, g.h, g.ldh, c0n + sp, g.B, rsrc_h);
     const int cc = min(c0n + lane, g.B - 1);
     if (g.lrow) row_n[0] = g.lrow[g.lrow_n == 1 ? 0 : cc];
     if (!IS_BER && MODE != MODE_NB_STATS && g.rowlse) row_n[1] = g.rowlse[cc];
-    if (MODE == MODE_NB_GRAD && g.rowT) row_n[2] = g.rowT[cc];
+    if (NB_GRAD && g.rowT) row_n[2] = g.rowT[cc];
   };
   // registers -> row-major image [NS][64][LDK_] (8-byte stores); rows past the end and the K-padding columns arrive as
   // zeros from either load path.  No transposed images: the dW / dh products read these through the transposing LDS
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       float fcol = 1.f;
       if (g.fs && f_ok) fcol = sigm_<FAST>(fs_c);
       float thcol = 0.f;
-      if (!IS_BER && g.theta_param && f_ok) thcol = exp_<FAST>(th_c);
+      if (THP && f_ok) thcol = exp_<FAST>(th_c);
       float dzv[16];
       float lsum = 0.f;     // fp32 partial of this tile, folded into the fp64 accumulator once per tile
       // Bernoulli, interior tile with 0/1 labels only: no bounds / NaN / soft-label handling (same algebra)
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
           dfs_acc[0] += (su2[0] + su2[1]) * (1.f - fcol);
           db_acc[0] += sd2[0] + sd2[1];
         }
-      } else if (MODE == MODE_NB_LOSS && (f0 + FT <= g.F) && (c0 + CB <= g.B)) {
+      } else if (NB_LOSS && (f0 + FT <= g.F) && (c0 + CB <= g.B)) {
         // NB likelihood pass, interior tile.  Phase 1 treats every label as 0 in straight-line code (the transcendental
         // chains of a group of elements interleave); phase 2 adds the terms of the non-zero labels (data-dependent
         // loops).  Same algebra as the general loop below.  (The GRAD pass keeps the general loop: the same split
@@ -446,9 +454,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             const float L = rowv[cl], lse = rowv[CB + cl];
             const float scale = exp_<FAST>(ap - lse);
             const float mu = L * scale;
-            const float th = g.theta_param ? thcol : exp_<FAST>(a_);
+            const float th = THP ? thcol : exp_<FAST>(a_);
             const float s_ = th + mu + eps;
-            const float lt = log_<FAST>(th + eps), ls = log_<FAST>(s_);
+            const float lt = (THP || !FAST) ? log_<FAST>(th + eps) : a_, ls = log_<FAST>(s_);
             const float rs = div_<FAST>(1.f, s_);
             const float gmu = -th * rs;
             mu_[j] = mu;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             const int cl = ti * 32 + acc_row(e, lane);
             const float yv = ytile[cl * FT + fl];
             if (yv > eps) {
-              const float th = g.theta_param ? thcol : exp_<FAST>(fmaxf(acc[e] + bcol, 0.f));
+              const float th = THP ? thcol : exp_<FAST>(fmaxf(acc[e] + bcol, 0.f));
               const float mu = mu_[j];
               const float gnz = yv * (div_<FAST>(1.f, mu + eps) - rs_[j]);
               lsum -= yv * (log_<FAST>(mu + eps) - ls_[j]) + lgam3<FAST>(yv, th);
@@ -517,25 +525,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             float L = rowv[cl], lse = rowv[CB + cl];
             float scale = exp_<FAST>(ap - lse);
             float mu = L * scale;
-            float th = g.theta_param ? thcol : exp_<FAST>(a_);
+            float th = THP ? thcol : exp_<FAST>(a_);
             float s_ = th + mu + eps;
-            float lt = log_<FAST>(th + eps), ls = log_<FAST>(s_);
+            float lt = (THP || !FAST) ? log_<FAST>(th + eps) : a_, ls = log_<FAST>(s_);
             float yv = ytile[cl * FT + fl];
             float rs = div_<FAST>(1.f, s_);
             float gmu = -th * rs;
             if (yv > eps) gmu += yv * (div_<FAST>(1.f, mu + eps) - rs);
-            if (MODE == MODE_NB_LOSS) {
+            if (NB_LOSS) {
               float ll = th * (lt - ls);
               if (yv > eps) ll += yv * (log_<FAST>(mu + eps) - ls) + lgam3<FAST>(yv, th);
               lsum -= ll;
               racc0[e] += gmu * mu;
             } else {   // MODE_NB_GRAD
-              float gth = lt - ls + div_<FAST>(th, th + eps) - th * rs;
+              float gth = lt - ls + ((THP || !FAST) ? div_<FAST>(th, th + eps) : 1.f) - th * rs;
               if (yv > eps) gth += -yv * rs + digam2<FAST>(yv, th);
               float T = rowv[2 * CB + cl];
               float dap = mu * gmu - scale * T;
               float da = dap * fcol;
-              if (g.theta_param)
+              if (THP)
                 dth_acc[0] -= gth * th;
               else
                 da += gth * th;
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         }
       }
     }
-    if (MODE == MODE_BER_TRAIN || MODE == MODE_NB_LOSS || MODE == MODE_NB_STATS) {
+    if (MODE == MODE_BER_TRAIN || NB_LOSS || MODE == MODE_NB_STATS) {
       // Row reductions over the 64 feature columns of the chunk's tiles: the per-lane partials go through an LDS
       // tile rt[cell][65] (odd stride: conflict-free both ways; it reuses the dZ images, idle here) and are summed
       // by 4 threads per cell in a fixed order.
@@ -681,7 +689,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   }  // cell blocks
 
   // ---- chunk-level outputs ------------------------------------------------------------------------
-  if (MODE != MODE_NB_STATS && MODE != MODE_NB_GRAD) {
+  if (MODE != MODE_NB_STATS && !NB_GRAD) {
     double s = block_sum_d(loss_acc, dred);
     if (tid == 0) g.loss_part[bid] = s;
   }
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 
 #define DEC_NPT 2        // feature tiles per chunk, training passes (a dW accumulator tile per feature tile stays in registers)
 #define DEC_NPT_EVAL 4   // passes without gradients: the h block is staged and the row reductions run once per 4 tiles
-template <int MODE> constexpr int dec_npt() { return (MODE == MODE_BER_TRAIN || MODE == MODE_NB_GRAD) ? DEC_NPT : DEC_NPT_EVAL; }
+template <int MODE> constexpr int dec_npt() { return (MODE == MODE_BER_TRAIN || MODE == MODE_NB_GRAD || MODE == MODE_NB_GRAD_TH) ? DEC_NPT : DEC_NPT_EVAL; }
 
 template <int NS, int KP>
 static size_t dec_smem() {
