@@ -1693,6 +1693,9 @@ _ADAM_FMT = _struct.Struct("@PPPPqfffffPqqqPq")     # ScpAdamTensor, packed with
 assert _ADAM_FMT.size == C.sizeof(_lib.AdamTensor)
 
 
+_NOCACHE = bool(_os.environ.get("SCPAIR_ADAM_NOCACHE"))      # A/B measurements of step()'s per-parameter cache
+
+
 class FusedAdamW(torch.optim.Optimizer):
     """Drop-in for torch.optim.AdamW as the reference configures it (model.py:698-701): same param_groups
     / state layout ('step', 'exp_avg', 'exp_avg_sq'), one fused multi-tensor HIP launch per step."""
@@ -1704,10 +1707,16 @@ class FusedAdamW(torch.optim.Optimizer):
         self._grads_released = False    # the last step() set every gradient it consumed to None
         self.last_step_numel = (0, 0)
         self._checked = {}              # id(p) -> data_ptr whose device / contiguity checks have passed
+        self._pc = {}                   # id(p) -> (p, data_ptr, state dict, exp_avg ptr, exp_avg_sq ptr, numel, last dim): the
+                                        # per-parameter constants of step() for plain contiguous parameters without a shadow
         self._bufs = {}                 # (beta1, beta2, eps) -> bytearray of packed ScpAdamTensor descriptors
         self.step_state = None          # StepState while a step of this optimiser is being captured / replayed
         self._dyn_params = {}           # id(p) -> p: parameters the captured step updates
         self._dyn_betas = None
+
+    def __setstate__(self, state):
+        super().__setstate__(state)     # load_state_dict() lands here with fresh state dicts: the cached ones are stale
+        self._pc = {}
 
     # -- a step captured in a HIP graph: 'step' counters advance on the host, bias corrections live on the device ---
     def _dyn_note(self, p, betas):
@@ -1801,6 +1810,7 @@ class FusedAdamW(torch.optim.Optimizer):
         keep = []
         dyn = self.step_state
         checked = self._checked
+        pc = self._pc
         released = release_grads
         n32 = n16 = 0
         for group in self.param_groups:
@@ -1821,6 +1831,27 @@ class FusedAdamW(torch.optim.Optimizer):
                     continue
                 g16 = 0
                 g = p.grad
+                ce = pc.get(id(p)) if (g is not None and dyn is None and not _NOCACHE) else None
+                if ce is not None and ce[0] is p and g.is_contiguous():
+                    # fast path: a plain contiguous parameter whose storage, moments and (absent) shadow are as cached
+                    st = ce[2]
+                    ea = st.get("exp_avg")
+                    if ce[1] == p.data_ptr() and ea is not None and ea.data_ptr() == ce[3] and id(p) not in _shadows:
+                        t = st["step"] = st["step"] + 1
+                        ent = by_hyper.get(key)
+                        if ent is None:
+                            ent = by_hyper[key] = [self._desc_buf(key), 0]
+                        buf, n = ent
+                        if (n + 1) * fmt.size > len(buf):
+                            buf.extend(bytes(len(buf)))
+                        fmt.pack_into(buf, n * fmt.size, ce[1], g.data_ptr(), ce[3], ce[4], ce[5], lr, wd, 1 - b1 ** t,
+                                      1 - b2 ** t, grad_scale, 0, ce[6], 0, 0, 0, 0)
+                        ent[1] = n + 1
+                        keep.append(g)
+                        n32 += ce[5]
+                        if released:
+                            p.grad = None
+                        continue
                 if g is None:
                     sk = _sinks.get(id(p)) if _sinks else None
                     if sk is None or not sk.written or sk.param is not p:
@@ -1864,6 +1895,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     n16 += p.numel()
                 else:
                     n32 += p.numel()
+                if dyn is None and not g16 and sh is None and ld_p == 0 and p.is_contiguous():
+                    pc[id(p)] = (p, pptr, st, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), p.shape[-1])
                 if released and not g16:
                     p.grad = None
         stream = _lib.stream()
