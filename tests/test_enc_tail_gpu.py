@@ -417,7 +417,7 @@ def _ref_bn(P, BN, x, rnd, training, cov=None, keep1=None, keep2=None):
 
 
 @pytest.mark.parametrize("B,F,H1,H2,N3,C", [(1024, 2000, 900, 40, 40, 0), (257, 700, 800, 30, 1, 4), (130, 333, 16, 8, 0, 0),
-                                            (67, 515, 1024, 64, 64, 3)])
+                                            (67, 515, 1024, 64, 64, 3), (9, 100, 4, 1, 1, 0), (3, 64, 260, 33, 7, 1)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_encoder_branch_with_batchnorm(B, F, H1, H2, N3, C, prec):
     """batchnorm=True encoders (the tutorial's configuration) on the fused tail: three forward segments with the
