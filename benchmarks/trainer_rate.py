@@ -1,0 +1,92 @@
+"""Rate of the product trainer itself -- `scPair_object.train_predicting_networks` (model.py:603-812 of the reference) at the C2
+shapes -- as opposed to `bench.py`'s own step loop: the same kernels, but driven by the trainer's epoch loop (DataLoader over
+row ids, tile lists built in line, one direction after the other, validation + checkpoint copy per epoch).
+
+Two runs with different epoch counts; the difference gives the cost of an epoch without the per-direction set-up (weight
+initialisation, homing of the first-layer weights, optimiser construction).  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+import scpair_amd as S
+from scpair_amd import synth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cells", type=int, default=20480)
+    ap.add_argument("--val", type=int, default=2048)
+    ap.add_argument("--genes", type=int, default=20000)
+    ap.add_argument("--peaks", type=int, default=100000)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--epochs", type=int, nargs=2, default=[2, 8])
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--profile", default=None, help="write a cProfile listing (by cumulative time) of the longer run here")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    mk = lambda n, s: (synth.make_rna_device(n, a.genes, dev, seed=100 + s, target_density=0.10),
+                       synth.make_atac_device(n, a.peaks, dev, seed=200 + s, p=0.03))
+    splits = {"train": mk(a.cells, 0), "val": mk(a.val, 1), "test": mk(64, 2)}
+    dicts = []
+    for split in ("train", "val", "test"):
+        r, p = splits[split]
+        dicts.append({f"Gene Expression_{split}_mtx": r, f"Peaks_{split}_mtx": p,
+                      f"Gene Expression_{split}_cov": None, f"Peaks_{split}_cov": None})
+
+    def run(epochs):
+        obj = S.scPair_object(None, cov=None, modalities={"Gene Expression": "nb", "Peaks": "ber"}, SEED=0,
+                              hidden_layer=[900, 40], dropout_rate=0.1, batch_size=a.batch, max_epochs=epochs,
+                              early_stopping_patience=1000, device=dev, save_model=False, zero_inflated=False,
+                              use_mixed_precision=(a.precision == "bf16"), verbose=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        obj.train_predicting_networks(*dicts)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = sum(len(h["train_loss"]) for h in obj.history.values())
+        last = {k: (h["train_loss"][-1], h["val_loss"][-1]) for k, h in obj.history.items()}
+        obj.reference_embeddings()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        obj.train_bidirectional_mapping()          # model.py:813-924: the two 40 -> 40 mapping nets, same epoch control
+        torch.cuda.synchronize()
+        return dt, steps, last, time.perf_counter() - t1
+
+    run(1)                                   # warm-up: library load, allocator pools
+    t_lo, s_lo, _, m_lo = run(a.epochs[0])
+    if a.profile:
+        import cProfile
+        import pstats
+        prof = cProfile.Profile()
+        prof.enable()
+    t_hi, s_hi, last, m_hi = run(a.epochs[1])
+    if a.profile:
+        prof.disable()
+        with open(a.profile, "w") as fh:
+            pstats.Stats(prof, stream=fh).sort_stats("cumulative").print_stats(60)
+    d_ep = a.epochs[1] - a.epochs[0]
+    per_epoch = (t_hi - t_lo) / d_ep         # both directions: one epoch of each predictor, validation and checkpoint copy included
+    steps_per_epoch = (s_hi - s_lo) / d_ep   # direction steps per epoch pair
+    print(json.dumps({
+        "what": "scPair_object.train_predicting_networks, C2 shapes, both predictors one after the other; marginal cost of an "
+                "epoch (training steps + validation over the val split + deepcopy of the best modules) from two runs",
+        "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
+        "seconds": [round(t_lo, 4), round(t_hi, 4)],
+        "ms_per_epoch_pair": round(1e3 * per_epoch, 3),
+        "ms_per_direction_step_incl_validation": round(1e3 * per_epoch / steps_per_epoch, 4),
+        "paired_cells_per_s": round(a.cells / per_epoch, 1),
+        "setup_s_per_run": round(t_lo - a.epochs[0] * per_epoch, 3),
+        "mapping_ms_per_epoch_pair": round(1e3 * (m_hi - m_lo) / d_ep, 3),
+        "mapping_paired_cells_per_s": round(a.cells * d_ep / (m_hi - m_lo), 1),
+        "last_losses": {k: [float(v[0]), float(v[1])] for k, v in last.items()},
+    }))
+
+
+if __name__ == "__main__":
+    main()

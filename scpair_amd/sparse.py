@@ -12,6 +12,18 @@ import torch
 from . import _lib
 
 
+def rows_to_device(rows_host: np.ndarray, device):
+    """Row ids of a minibatch -> int64 device tensor without stalling the host: a copy from pageable memory waits for the
+    stream to drain (every kernel of the previous step), which leaves the GPU idle while the next step is enqueued; staged
+    through pinned memory (torch's caching host allocator keeps the block until the copy has run) it is stream-ordered
+    only."""
+    t = torch.from_numpy(np.ascontiguousarray(rows_host, dtype=np.int64))
+    device = torch.device(device)
+    if device.type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 class DeviceCSR:
     """CSR cell x feature matrix in GPU memory (int64 indptr, int32 indices, fp32 values or implicit ones)."""
 
@@ -205,7 +217,7 @@ class BatchTiles:
                     rows_host = rows.detach().cpu().numpy()
             else:
                 rows_host = np.asarray(rows, dtype=np.int64)
-                rows_dev = torch.from_numpy(rows_host).to(dev)
+                rows_dev = rows_to_device(rows_host, dev)
             rows_host = np.asarray(rows_host, dtype=np.int64)
             self.B = int(rows_host.shape[0])
             if self.B and (rows_host.min() < 0 or rows_host.max() >= csr.n_rows):

@@ -20,7 +20,7 @@ from torch import nn
 
 from . import ops
 from .pairedVAE import VAE_DECODER, VAE_ENCODER
-from .sparse import BatchTiles
+from .sparse import BatchTiles, rows_to_device
 from .utils import _vae_losses, add_weight_decay, init_weights, set_seed
 
 
@@ -160,7 +160,7 @@ class scVAE_object:
                         self.history["train_loss"].append(self._dp_step(None, 0.0, opt, True))
                         continue
                 rows = np.asarray(rows, dtype=np.int64)
-                rows_dev = torch.from_numpy(rows).to(self.device)
+                rows_dev = rows_to_device(rows, self.device)
                 t = BatchTiles(xtr, rows_dev, want_lib=True, rows_host=rows)
                 c = None if ctr is None else ctr[rows_dev]
                 x = t.to_dense() if dense_in else t
