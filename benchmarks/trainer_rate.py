@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--epochs", type=int, nargs=2, default=[2, 8])
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--vae", action="store_true", help="the unimodal VAE trainer (scVAE_object.train) at the C4 shapes instead")
     ap.add_argument("--profile", default=None, help="write a cProfile listing (by cumulative time) of the longer run here")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -39,7 +40,20 @@ def main():
         dicts.append({f"Gene Expression_{split}_mtx": r, f"Peaks_{split}_mtx": p,
                       f"Gene Expression_{split}_cov": None, f"Peaks_{split}_cov": None})
 
+    def run_vae(epochs):
+        obj = S.scVAE_object(distribution="nb", SEED=0, hidden_dim=[900], latent_dim=40, dropout_rate=0.1, batch_size=a.batch,
+                             max_epochs=epochs, early_stopping_patience=1000, device=dev, save_model=False,
+                             use_mixed_precision=(a.precision == "bf16"), verbose=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        obj.train(splits["train"][0], splits["val"][0])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, len(obj.history["train_loss"]), {"vae": (obj.history["train_loss"][-1], obj.history["val_loss"][-1])}, 0.0
+
     def run(epochs):
+        if a.vae:
+            return run_vae(epochs)
         obj = S.scPair_object(None, cov=None, modalities={"Gene Expression": "nb", "Peaks": "ber"}, SEED=0,
                               hidden_layer=[900, 40], dropout_rate=0.1, batch_size=a.batch, max_epochs=epochs,
                               early_stopping_patience=1000, device=dev, save_model=False, zero_inflated=False,
@@ -74,16 +88,18 @@ def main():
     per_epoch = (t_hi - t_lo) / d_ep         # both directions: one epoch of each predictor, validation and checkpoint copy included
     steps_per_epoch = (s_hi - s_lo) / d_ep   # direction steps per epoch pair
     print(json.dumps({
-        "what": "scPair_object.train_predicting_networks, C2 shapes, both predictors one after the other; marginal cost of an "
-                "epoch (training steps + validation over the val split + deepcopy of the best modules) from two runs",
+        "what": ("scVAE_object.train, C4 shapes (unimodal NB VAE)" if a.vae else
+                 "scPair_object.train_predicting_networks, C2 shapes, both predictors one after the other") +
+                "; marginal cost of an epoch (training steps + validation over the val split + deepcopy of the best modules) "
+                "from two runs",
         "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
         "seconds": [round(t_lo, 4), round(t_hi, 4)],
         "ms_per_epoch_pair": round(1e3 * per_epoch, 3),
         "ms_per_direction_step_incl_validation": round(1e3 * per_epoch / steps_per_epoch, 4),
-        "paired_cells_per_s": round(a.cells / per_epoch, 1),
+        "cells_per_s": round(a.cells / per_epoch, 1),
         "setup_s_per_run": round(t_lo - a.epochs[0] * per_epoch, 3),
-        "mapping_ms_per_epoch_pair": round(1e3 * (m_hi - m_lo) / d_ep, 3),
-        "mapping_paired_cells_per_s": round(a.cells * d_ep / (m_hi - m_lo), 1),
+        "mapping_ms_per_epoch_pair": None if a.vae else round(1e3 * (m_hi - m_lo) / d_ep, 3),
+        "mapping_paired_cells_per_s": None if a.vae else round(a.cells * d_ep / (m_hi - m_lo), 1),
         "last_losses": {k: [float(v[0]), float(v[1])] for k, v in last.items()},
     }))
 
