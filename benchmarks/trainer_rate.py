@@ -28,9 +28,22 @@ def main():
     ap.add_argument("--epochs", type=int, nargs=2, default=[2, 8])
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--vae", action="store_true", help="the unimodal VAE trainer (scVAE_object.train) at the C4 shapes instead")
+    ap.add_argument("--dp", choices=["none", "replicated", "sharded"], default="none",
+                    help="run the data-parallel trainer with ONE rank over RCCL (the call sequence and host cost of the N > 1 "
+                         "trainer on a one-GPU box): replicated weights, or feature-sharded first layers")
     ap.add_argument("--profile", default=None, help="write a cProfile listing (by cumulative time) of the longer run here")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    sync = None
+    if a.dp != "none":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from scpair_amd.distributed import GradSync
+        S.set_precision(a.precision)
+        sync = GradSync(compress=(a.precision == "bf16"))
     mk = lambda n, s: (synth.make_rna_device(n, a.genes, dev, seed=100 + s, target_density=0.10),
                        synth.make_atac_device(n, a.peaks, dev, seed=200 + s, p=0.03))
     splits = {"train": mk(a.cells, 0), "val": mk(a.val, 1), "test": mk(64, 2)}
@@ -57,7 +70,8 @@ def main():
         obj = S.scPair_object(None, cov=None, modalities={"Gene Expression": "nb", "Peaks": "ber"}, SEED=0,
                               hidden_layer=[900, 40], dropout_rate=0.1, batch_size=a.batch, max_epochs=epochs,
                               early_stopping_patience=1000, device=dev, save_model=False, zero_inflated=False,
-                              use_mixed_precision=(a.precision == "bf16"), verbose=False)
+                              use_mixed_precision=(a.precision == "bf16"), verbose=False, grad_sync=sync,
+                              shard_first_layer=(a.dp == "sharded"))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         obj.train_predicting_networks(*dicts)
@@ -92,7 +106,7 @@ def main():
                  "scPair_object.train_predicting_networks, C2 shapes, both predictors one after the other") +
                 "; marginal cost of an epoch (training steps + validation over the val split + deepcopy of the best modules) "
                 "from two runs",
-        "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
+        "data_parallel": a.dp, "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
         "seconds": [round(t_lo, 4), round(t_hi, 4)],
         "ms_per_epoch_pair": round(1e3 * per_epoch, 3),
         "ms_per_direction_step_incl_validation": round(1e3 * per_epoch / steps_per_epoch, 4),

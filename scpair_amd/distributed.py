@@ -15,6 +15,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .sparse import scalar64 as _scalar64
+
 
 class GradSync:
     def __init__(self, group=None, big: int = 1 << 20, compress: bool = False):
@@ -80,7 +82,7 @@ class GradSync:
     def share_of(self, n_valid, device):
         """This rank's share n_r / n_total of a step's valid label elements (one small SUM all-reduce): the weight its
         loss carries in the global-batch loss.  A device scalar."""
-        nv = torch.as_tensor(n_valid, dtype=torch.float64, device=device).reshape(1).clone()
+        nv = _scalar64(n_valid, device).reshape(1).clone()
         tot = self._sum(nv.clone())
         return (nv / torch.clamp(tot, min=1.0)).to(torch.float32).reshape(())      # no valid label anywhere: shares 0
 
@@ -157,7 +159,7 @@ class GradSync:
     def all_reduce_grads(self, params, n_valid):
         """Global-batch gradient: each rank scales its mean-gradient by n_r / n_total, then SUM all-reduce."""
         dev = params[0].device
-        nv = torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(1).clone()
+        nv = _scalar64(n_valid, dev).reshape(1).clone()
         tot = self._sum(nv.clone())
         w = (nv / torch.clamp(tot, min=1.0)).to(torch.float32)
         grads = [p.grad for p in params if p.grad is not None]
@@ -194,14 +196,26 @@ class GradSync:
             for h_ in sink[1]:
                 h_.written = True
 
-    def exchange(self, params, n_valid, loss, sink=None, some_rank_empty=False):
+    def step_scalars(self, n_valid, loss, device):
+        """The step's one small collective: SUM over the ranks of (valid label elements, loss x valid label elements).
+        Returns (this rank's count, the summed pair) as float64 device tensors.  `loss` None: this rank's shard was empty."""
+        nv = _scalar64(n_valid, device)
+        lv = torch.zeros((), dtype=torch.float64, device=device) if loss is None else loss.detach().double().reshape(())
+        return nv, self._sum(torch.stack([nv, lv * nv]))
+
+    @staticmethod
+    def share_from(scalars):
+        """n_r / n_total (float32 device scalar) from step_scalars()'s result; 0 when no rank has a valid label."""
+        nv, v = scalars
+        return (nv / torch.clamp(v[0], min=1.0)).to(torch.float32).reshape(())
+
+    def exchange(self, params, n_valid, loss, sink=None, some_rank_empty=False, scalars=None):
         """After backward() on this rank's shard: one small collective for the step's scalars (this rank's number of
-        valid label elements and its loss), gradients scaled by n_r / n_total in one multi-tensor launch, the bucketed
+        valid label elements and its loss; `scalars`: the result of step_scalars() when the caller needed it before the
+        backward pass already), gradients scaled by n_r / n_total in one multi-tensor launch, the bucketed
         SUM all-reduce.  `loss` None / n_valid 0: this rank's shard was empty.  Returns the global-batch loss."""
         dev = params[0].device
-        nv = torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(())
-        lv = torch.zeros((), dtype=torch.float64, device=dev) if loss is None else loss.detach().double().reshape(())
-        v = self._sum(torch.stack([nv, lv * nv]))
+        nv, v = scalars if scalars is not None else self.step_scalars(n_valid, loss, dev)
         w = (nv / torch.clamp(v[0], min=1.0)).to(torch.float32)
         if some_rank_empty:
             self._align_grads(params, sink)
@@ -216,8 +230,8 @@ class GradSync:
 
     def weighted_mean(self, value, n_valid):
         dev = value.device
-        v = torch.stack([value.double() * torch.as_tensor(n_valid, dtype=torch.float64, device=dev),
-                         torch.as_tensor(n_valid, dtype=torch.float64, device=dev).reshape(())])
+        nv = _scalar64(n_valid, dev)
+        v = torch.stack([value.double().reshape(()) * nv, nv])
         self._sum(v)
         return (v[0] / v[1]).to(value.dtype)
 

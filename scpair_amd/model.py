@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .loss import binarized_loss, raw_loss, scaled_loss
-from .sparse import BatchTiles, DeviceCSR, rows_to_device
+from .sparse import BatchTiles, DeviceCSR, rows_to_device, scalar64
 from .utils import (FCNN, HipLinear, add_weight_decay, encoder_branches, eval_net, evaluating_mode, init_weights,
                     set_seed, train_net, training_mode)
 
@@ -670,7 +670,7 @@ class scPair_object():
                 lib = ty.lib.reshape(-1, 1) if use_lib else None
                 loss = eval_net(tx, ty, lib, encoder, decoder, likelihood, add_cov=False, input_batch=None, output_batch=None)
                 cnt = float(len(rows) * ycsr.n_cols) - (ty.nnan.double()[0] if likelihood == "ber" else 0.0)
-                cnt = torch.as_tensor(cnt, dtype=torch.float64, device=self.device)
+                cnt = scalar64(cnt, self.device)
                 num += loss.double() * cnt
                 den += cnt
                 continue
@@ -681,12 +681,12 @@ class scPair_object():
             if likelihood == "gau":
                 loss = eval_net(tx, ty.to_dense(), lib, encoder, decoder, likelihood,
                                 add_cov=c is not None, input_batch=c, output_batch=c)
-                cnt = torch.tensor(float(len(rows) * ycsr.n_cols), dtype=torch.float64, device=self.device)
+                cnt = scalar64(float(len(rows) * ycsr.n_cols), self.device)
             else:
                 loss = eval_net(tx, ty, lib, encoder, decoder, likelihood, add_cov=c is not None, input_batch=c,
                                 output_batch=c)
                 cnt = float(len(rows) * ycsr.n_cols) - (ty.nnan.double()[0] if likelihood == "ber" else 0.0)
-                cnt = torch.as_tensor(cnt, dtype=torch.float64, device=self.device)
+                cnt = scalar64(cnt, self.device)
             num += loss.double() * cnt
             den += cnt
         if self.grad_sync is not None:
@@ -865,7 +865,7 @@ class scPair_object():
             opt._dp_sink = self.grad_sync.make_sink(firsts)
         return firsts
 
-    def _dp_step(self, loss, n_valid, optimizer, some_rank_empty=False):
+    def _dp_step(self, loss, n_valid, optimizer, some_rank_empty=False, scalars=None):
         """Data-parallel tail of one optimisation step: backward on this rank's shard (loss None: empty shard), the
         gradient exchange, the identical AdamW step on every rank.  Returns the global-batch loss."""
         optimizer.zero_grad()
@@ -875,7 +875,7 @@ class scPair_object():
             loss.backward()
         params = [p for g in optimizer.param_groups for p in g['params'] if not getattr(p, "_scp_feature_sharded", False)]
         gl = self.grad_sync.exchange(params, n_valid, loss, sink=getattr(optimizer, '_dp_sink', None),
-                                     some_rank_empty=some_rank_empty)
+                                     some_rank_empty=some_rank_empty, scalars=scalars)
         optimizer.step()
         return gl
 
@@ -1022,9 +1022,11 @@ class scPair_object():
         n_valid = float(ty.shape[0] * ty.shape[1]) if not isinstance(ty, BatchTiles) or dist != "ber" else \
             (float(ty.B * ty.F) - ty.nnan.double()[0])
         shd = getattr(tx, "shard", None)
+        scalars = None
         if shd is not None:                       # read by the first layer's backward: weight of this rank's dY rows
-            shd.share = self.grad_sync.share_of(n_valid, self.device)
-        return self._dp_step(loss, n_valid, optimizer, some_rank_empty)
+            scalars = self.grad_sync.step_scalars(n_valid, loss, self.device)      # the step's one scalar collective, early
+            shd.share = self.grad_sync.share_from(scalars)
+        return self._dp_step(loss, n_valid, optimizer, some_rank_empty, scalars=scalars)
 
     def train_bidirectional_mapping(self):
         """model.py:813-924."""

@@ -24,6 +24,14 @@ def rows_to_device(rows_host: np.ndarray, device):
     return t.to(device)
 
 
+def scalar64(v, device):
+    """A float64 device scalar from a Python number (a fill kernel: no host-to-device copy, which from pageable memory would
+    wait for the stream to drain) or from a tensor."""
+    if torch.is_tensor(v):
+        return v.detach().to(device=device, dtype=torch.float64).reshape(())
+    return torch.full((), float(v), dtype=torch.float64, device=device)
+
+
 class DeviceCSR:
     """CSR cell x feature matrix in GPU memory (int64 indptr, int32 indices, fp32 values or implicit ones)."""
 

@@ -20,7 +20,7 @@ from torch import nn
 
 from . import ops
 from .pairedVAE import VAE_DECODER, VAE_ENCODER
-from .sparse import BatchTiles, rows_to_device
+from .sparse import BatchTiles, rows_to_device, scalar64
 from .utils import _vae_losses, add_weight_decay, init_weights, set_seed
 
 
@@ -107,8 +107,8 @@ class scVAE_object:
             x = t if self.distribution in ("nb", "zinb") else t.to_dense()
             _, recon, kl = _vae_losses(x, self._lib(t), enc, dec, self.kl_weight, self.distribution, c is not None, c)
             n = float(len(rows))
-            acc += torch.stack([recon.double() * n, torch.tensor(n, dtype=torch.float64, device=self.device),
-                                kl.double() * n, torch.tensor(n, dtype=torch.float64, device=self.device)])
+            n_dev = scalar64(n, self.device)
+            acc += torch.stack([recon.double() * n, n_dev, kl.double() * n, n_dev])
         if self.grad_sync is not None:
             self.grad_sync._sum(acc)
         recon, kl = acc[0] / acc[1], acc[2] / acc[3]
