@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--dp", choices=["none", "replicated", "sharded"], default="none",
                     help="run the data-parallel trainer with ONE rank over RCCL (the call sequence and host cost of the N > 1 "
                          "trainer on a one-GPU box): replicated weights, or feature-sharded first layers")
+    ap.add_argument("--explicit-peak-values", action="store_true",
+                    help="hold the binary peak matrices WITH a value array of ones (what the trainer's data seam did with a "
+                         "binarised scipy matrix before it detected all-ones data): the value-carrying kernel paths")
     ap.add_argument("--profile", default=None, help="write a cProfile listing (by cumulative time) of the longer run here")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -47,6 +50,8 @@ def main():
     mk = lambda n, s: (synth.make_rna_device(n, a.genes, dev, seed=100 + s, target_density=0.10),
                        synth.make_atac_device(n, a.peaks, dev, seed=200 + s, p=0.03))
     splits = {"train": mk(a.cells, 0), "val": mk(a.val, 1), "test": mk(64, 2)}
+    if a.explicit_peak_values:
+        splits = {k: (r, p.with_explicit_values()) for k, (r, p) in splits.items()}
     dicts = []
     for split in ("train", "val", "test"):
         r, p = splits[split]
@@ -106,7 +111,7 @@ def main():
                  "scPair_object.train_predicting_networks, C2 shapes, both predictors one after the other") +
                 "; marginal cost of an epoch (training steps + validation over the val split + deepcopy of the best modules) "
                 "from two runs",
-        "data_parallel": a.dp, "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
+        "data_parallel": a.dp, "explicit_peak_values": bool(a.explicit_peak_values), "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
         "seconds": [round(t_lo, 4), round(t_hi, 4)],
         "ms_per_epoch_pair": round(1e3 * per_epoch, 3),
         "ms_per_direction_step_incl_validation": round(1e3 * per_epoch / steps_per_epoch, 4),

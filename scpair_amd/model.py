@@ -316,12 +316,14 @@ class _Index:
         self.index = np.arange(n)
 
 
-def _to_csr(v, device, binary=False):
-    """dict-seam value -> DeviceCSR.  Accepts the reference's dense FloatTensor, scipy sparse, or DeviceCSR."""
+def _to_csr(v, device, binary=None):
+    """dict-seam value -> DeviceCSR.  Accepts the reference's dense FloatTensor, scipy sparse, or DeviceCSR.  binary=None:
+    a matrix whose stored entries are all 1 (binarised peaks) is held without a value array, which puts it on the kernels'
+    implicit-ones path (same numbers: the value 1 is exact in every operand format)."""
     if isinstance(v, DeviceCSR):
         return v
     if isinstance(v, torch.Tensor) or isinstance(v, np.ndarray):
-        return DeviceCSR.from_dense(v, device)
+        return DeviceCSR.from_dense(v, device, binary=binary)
     return DeviceCSR.from_scipy(v, device, binary=binary)
 
 
@@ -609,7 +611,7 @@ class scPair_object():
             tf = next((v for m, v in self.input_transform.items() if key.startswith(m + '_')), None)
             if tf is not None:
                 mode, scale = (tf[0], tf[1]) if isinstance(tf, (tuple, list)) else (tf, 1e4)
-                csr = csr.with_transform(mode, scale)
+                csr = csr.with_explicit_values().with_transform(mode, scale)
         return csr
 
     def run(self):

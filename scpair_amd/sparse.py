@@ -74,24 +74,40 @@ class DeviceCSR:
 
     @classmethod
     def from_scipy(cls, m, device="cuda", binary=False):
-        """Canonical CSR required (duplicates summed, indices sorted): scipy's .sum_duplicates() does both."""
+        """Canonical CSR required (duplicates summed, indices sorted): scipy's .sum_duplicates() does both.
+        binary: True = every stored entry is taken to be 1 (no value array: the kernels' implicit-ones path, less traffic
+        and no value scatter); None = decided from the data (all stored values equal to 1, e.g. binarised peaks)."""
         import scipy.sparse as sp
         m = sp.csr_matrix(m)
         if not m.has_canonical_format:
             m = m.copy()
             m.sum_duplicates()
+        if binary is None:
+            binary = bool(m.data.size) and bool(np.all(m.data == 1))
         vals = None if binary else m.data
         return cls(m.indptr, m.indices, vals, m.shape, device)
 
     @classmethod
-    def from_dense(cls, x, device="cuda"):
-        """Dense tensor / array -> CSR.  NaN entries (missing labels, loss.py:24,38) are kept as explicit entries."""
+    def from_dense(cls, x, device="cuda", binary=False):
+        """Dense tensor / array -> CSR.  NaN entries (missing labels, loss.py:24,38) are kept as explicit entries.
+        binary=None: implicit ones when every non-zero entry is 1 (see from_scipy)."""
         import scipy.sparse as sp
         a = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
         mask = (a != 0) | np.isnan(a)
         rows, cols = np.nonzero(mask)
         m = sp.csr_matrix((a[rows, cols].astype(np.float32), (rows, cols)), shape=a.shape)
-        return cls(m.indptr, m.indices, m.data, m.shape, device)
+        if binary is None:
+            binary = bool(m.data.size) and bool(np.all(m.data == 1))
+        return cls(m.indptr, m.indices, None if binary else m.data, m.shape, device)
+
+    def with_explicit_values(self):
+        """The same matrix with a value array (ones) where the entries are implicit ones; self otherwise."""
+        if self.values is not None:
+            return self
+        import copy
+        v = copy.copy(self)
+        v.values = torch.ones(max(self.nnz, 1), dtype=torch.float32, device=self.device)
+        return v
 
     # Optional input pre-transform (opt-in; the reference feeds raw counts): None, ("log1p", 1.0) or
     # ("log1p_norm", scale).  It is applied to every minibatch tile list built from this object, on the batch's own

@@ -71,6 +71,35 @@ def test_index_loader_is_the_shuffling_dataloader(n, bs, drop_last):
             np.testing.assert_array_equal(a, b)
 
 
+def test_all_ones_matrices_are_held_without_values():
+    """The trainers' data seam (model._to_csr) keeps a matrix whose stored entries are all 1 (binarised peaks) without a value
+    array, so that it runs the kernels' implicit-ones path; counts, explicit zeros and NaN labels keep their values."""
+    import scipy.sparse as sp
+    from scpair_amd.model import _to_csr
+    rng = np.random.default_rng(0)
+    ones = sp.random(50, 40, density=0.1, format="csr", random_state=1, dtype=np.float32)
+    ones.data[:] = 1.0
+    assert _to_csr(ones, "cpu").values is None
+    assert _to_csr(torch.tensor(ones.toarray()), "cpu").values is None
+    assert S.DeviceCSR.from_scipy(ones, "cpu").values is not None          # the explicit constructor keeps its default
+    counts = ones.copy()
+    counts.data[3] = 2.0
+    assert _to_csr(counts, "cpu").values is not None
+    nan = ones.copy()
+    nan.data[5] = np.nan
+    assert _to_csr(nan, "cpu").values is not None
+    dense_nan = ones.toarray()
+    dense_nan[0, 0] = np.nan
+    assert _to_csr(dense_nan, "cpu").values is not None
+    empty = sp.csr_matrix((4, 7), dtype=np.float32)
+    assert _to_csr(empty, "cpu").values is not None                        # nothing stored: nothing to decide from
+    c = _to_csr(ones, "cpu")
+    e = c.with_explicit_values()
+    assert e.values is not None and float(e.values.sum()) == c.nnz and e.indices is c.indices
+    assert c.with_explicit_values().with_transform("log1p").transform == ("log1p", 1.0)
+    del rng
+
+
 def test_weight_decay_groups_equal_reference():
     with open(os.path.join(U.GOLD, "weight_decay_groups.json")) as f:
         groups = json.load(f)
