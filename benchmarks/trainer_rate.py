@@ -1,6 +1,7 @@
 """Rate of the product trainer itself -- `scPair_object.train_predicting_networks` (model.py:603-812 of the reference) at the C2
 shapes -- as opposed to `bench.py`'s own step loop: the same kernels, but driven by the trainer's epoch loop (DataLoader over
-row ids, tile lists built in line, one direction after the other, validation + checkpoint copy per epoch).
+row ids, tile lists built in line, validation + checkpoint copy per epoch; the two directions side by side on two streams,
+or one after the other with --sequential).
 
 Two runs with different epoch counts; the difference gives the cost of an epoch without the per-direction set-up (weight
 initialisation, homing of the first-layer weights, optimiser construction).  Prints one JSON line."""
@@ -34,6 +35,8 @@ def main():
     ap.add_argument("--explicit-peak-values", action="store_true",
                     help="hold the binary peak matrices WITH a value array of ones (what the trainer's data seam did with a "
                          "binarised scipy matrix before it detected all-ones data): the value-carrying kernel paths")
+    ap.add_argument("--sequential", action="store_true",
+                    help="train the predictors one after the other (the reference's order) instead of side by side")
     ap.add_argument("--profile", default=None, help="write a cProfile listing (by cumulative time) of the longer run here")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -76,7 +79,7 @@ def main():
                               hidden_layer=[900, 40], dropout_rate=0.1, batch_size=a.batch, max_epochs=epochs,
                               early_stopping_patience=1000, device=dev, save_model=False, zero_inflated=False,
                               use_mixed_precision=(a.precision == "bf16"), verbose=False, grad_sync=sync,
-                              shard_first_layer=(a.dp == "sharded"))
+                              shard_first_layer=(a.dp == "sharded"), concurrent_directions=not a.sequential)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         obj.train_predicting_networks(*dicts)
@@ -108,10 +111,11 @@ def main():
     steps_per_epoch = (s_hi - s_lo) / d_ep   # direction steps per epoch pair
     print(json.dumps({
         "what": ("scVAE_object.train, C4 shapes (unimodal NB VAE)" if a.vae else
-                 "scPair_object.train_predicting_networks, C2 shapes, both predictors one after the other") +
+                 "scPair_object.train_predicting_networks, C2 shapes, both predictors " +
+                 ("one after the other" if (a.sequential or a.dp != "none") else "side by side on two streams")) +
                 "; marginal cost of an epoch (training steps + validation over the val split + deepcopy of the best modules) "
                 "from two runs",
-        "data_parallel": a.dp, "explicit_peak_values": bool(a.explicit_peak_values), "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
+        "data_parallel": a.dp, "sequential": bool(a.sequential), "explicit_peak_values": bool(a.explicit_peak_values), "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
         "seconds": [round(t_lo, 4), round(t_hi, 4)],
         "ms_per_epoch_pair": round(1e3 * per_epoch, 3),
         "ms_per_direction_step_incl_validation": round(1e3 * per_epoch / steps_per_epoch, 4),

@@ -11,6 +11,7 @@ What changes underneath:
 from __future__ import annotations
 
 import copy
+import itertools
 import gc
 import os
 
@@ -437,7 +438,7 @@ class scPair_object():
                  val_chunk=4096,
                  verbose=True,
                  grad_sync=None, fuse_optimizer=True, input_transform=None, capture_step=False,
-                 shard_first_layer=False):
+                 shard_first_layer=False, concurrent_directions=True):
         self.scobj = scobj
         self.modalities = modalities
         self.modality_names = list(modalities.keys())
@@ -491,6 +492,9 @@ class scPair_object():
         # (distributed.FirstLayerShard) instead of a replica whose dense gradient is all-reduced every step.  Needs the
         # fused encoder shape (no covariates, no BatchNorm) and global batches of at least `world` rows.
         self.shard_first_layer = bool(shard_first_layer) and grad_sync is not None
+        # single process: the two predictors are trained side by side, one stream each (same results as one after the
+        # other: each keeps its own stream of batch draws; only the numbering of dropout seeds differs)
+        self.concurrent_directions = bool(concurrent_directions)
         self.fuse_optimizer = fuse_optimizer  # AdamW step of the first-layer weights inside their dW kernel (1 process)
         # opt-in, single process: full-size minibatch steps are recorded once per direction as a HIP graph and
         # replayed (scpair_amd.graph.CapturedStep; same kernels in the same order, so results do not change)
@@ -894,6 +898,164 @@ class scPair_object():
         if getattr(self, "_dp_has_bn", False):
             ops.set_bn_sync(None if empty_somewhere else self.grad_sync)
 
+    def _concurrent_directions_ok(self, batch_replay):
+        """Both predictors trained side by side, each on its own stream (the two share nothing but the data): single
+        process, eager steps, sparse labels for both.  Off: `concurrent_directions=False` / SCPAIR_SEQUENTIAL_DIRECTIONS=1."""
+        return bool(self.concurrent_directions and not os.environ.get("SCPAIR_SEQUENTIAL_DIRECTIONS")
+                    and self.grad_sync is None and not self.capture_step and len(self.modality_names) == 2
+                    and 'gau' not in self.modality_distributions)
+
+    def _run_interleaved(self, tasks):
+        """Round-robin over the directions' tasks, one optimisation step (or one epoch end) at a time, each resumed under its
+        own stream: the kernels of one direction fill the gaps of the other (its HBM-bound weight-gradient + AdamW kernel
+        next to the other's MFMA- and vector-bound ones), as `bench.py`'s paired step does.  A task that has stopped
+        (early stopping, max_epochs) drops out; the other goes on alone."""
+        cur = torch.cuda.current_stream(self.device)
+        streams = [torch.cuda.Stream(self.device) for _ in tasks]
+        for s in streams:
+            s.wait_stream(cur)            # matrices, weights: created on the caller's stream
+        live = list(range(len(tasks)))
+        while live:
+            for i in list(live):
+                with torch.cuda.stream(streams[i]):
+                    try:
+                        next(tasks[i])
+                    except StopIteration:
+                        live.remove(i)
+        for s in streams:
+            cur.wait_stream(s)
+
+    def _predictor_task(self, di, input_modality, train_data_dict, val_data_dict, batch_replay, encoder_dict, decoder_dict,
+                        concurrent):
+        """One direction of train_predicting_networks (model.py:612-811) as a generator: run to exhaustion it is the
+        reference's loop; with `concurrent` it hands control back after set-up ("ready"), after every optimisation step and
+        after every epoch, so that _run_interleaved can alternate between the two directions."""
+
+        output_modality = self._other(input_modality)
+        prediction_order = {'input': input_modality, 'output': output_modality}
+        self._say('Set up predicting networks:', prediction_order)
+        xtr = self._csr(train_data_dict, input_modality + '_train_mtx', as_input=True)
+        ytr = self._csr(train_data_dict, output_modality + '_train_mtx')
+        xva = self._csr(val_data_dict, input_modality + '_val_mtx', as_input=True)
+        yva = self._csr(val_data_dict, output_modality + '_val_mtx')
+        ctr = self._cov_dev(train_data_dict, input_modality + '_train_cov')
+        cva = self._cov_dev(val_data_dict, input_modality + '_val_cov')
+        n_cov = 0 if ctr is None else ctr.shape[1]
+        dist = self.modalities[output_modality]
+        encoder, decoder, use_lib = self._build_predictor(input_modality, output_modality, xtr.n_cols, ytr.n_cols, n_cov)
+        shard = None
+        if self.grad_sync is not None:
+            self._check_dp(encoder, decoder)
+            self.grad_sync.broadcast(list(encoder.parameters()) + list(decoder.parameters()) +
+                                     list(encoder.buffers()) + list(decoder.buffers()))
+            if self.shard_first_layer:
+                if n_cov or self.batchnorm or dist == 'gau':
+                    raise ValueError("shard_first_layer needs cov=None, batchnorm=False and a count / Bernoulli output")
+                from .distributed import FirstLayerShard
+                shard = FirstLayerShard(self.grad_sync, xtr.n_cols)
+                shard.shard_module(encoder)
+                xtr_cols, xva_cols = shard.col_csr(xtr), shard.col_csr(xva)
+        optimizer = self._make_optimizer(encoder, decoder)
+        scheduler = self.get_scheduler(optimizer)
+        set_seed(self.SEED)
+        rng_state = torch.get_rng_state() if concurrent else None     # this direction's own stream of loader draws
+        loader = _index_loader(xtr.n_rows, self.batch_size) if batch_replay is None else None
+        ytr_dense = ytr.to_dense().to(self.device) if dist == 'gau' else None
+        if not self.early_stopping_activation:
+            raise TypeError("early_stopping_activation=False is unusable upstream (model.py:719, 786: "
+                            "`val < None`); keep it True")
+        patience, no_improve, min_val = self.early_stopping_patience, 0, np.inf
+        hist = {"train_loss": [], "val_loss": []}
+        replay = None if batch_replay is None else list(batch_replay[di])
+        per_epoch = None if replay is None else int(np.ceil(xtr.n_rows / self.batch_size))
+        encoder_ckpt = decoder_ckpt = None
+        stepper = _GraphStepper(self, xtr, ytr, ctr, use_lib, encoder, decoder, optimizer, dist) \
+            if (self.capture_step and self.grad_sync is None and scheduler is None and dist != 'gau') else None
+        if concurrent:
+            yield "ready"
+        for epoch in range(self.max_epochs):
+            training_mode(encoder, decoder)
+            if replay is not None:
+                batches = replay[epoch * per_epoch:(epoch + 1) * per_epoch]
+                if not batches:
+                    break
+            elif not concurrent:
+                batches = (b[0].numpy() for b in loader)
+            else:
+                # the loader draws from the global torch RNG when an epoch's iterator comes into being (its base seed and
+                # the sampler's seed); with the other direction's task interleaved, each direction keeps the RNG stream it
+                # would have had on its own, so batches are those of the one-after-the-other order
+                outer = torch.get_rng_state()
+                torch.set_rng_state(rng_state)
+                it = iter(loader)
+                first = next(it, None)
+                rng_state = torch.get_rng_state()
+                torch.set_rng_state(outer)
+                batches = (b[0].numpy() for b in itertools.chain(() if first is None else (first,), it))
+            step_losses = []
+            for rows in batches:
+                empty_somewhere = False
+                tx = None
+                if shard is not None:
+                    # feature-sharded first layer: the encoder input is the GLOBAL batch over this rank's columns
+                    tx, rows = shard.batch_tiles(xtr_cols, rows)
+                elif self.grad_sync is not None:
+                    empty_somewhere = self.grad_sync.some_rank_empty(len(rows))
+                    self._bn_step(empty_somewhere)
+                    rows = self.grad_sync.shard(rows)
+                    if len(rows) == 0:            # global batch smaller than the world: join the collectives only
+                        step_losses.append(self._dp_step(None, 0.0, optimizer, True))
+                        continue
+                rows = np.asarray(rows, dtype=np.int64)
+                rows_dev = rows_to_device(rows, self.device)          # one upload, shared by both modalities
+                if stepper is not None and stepper.wants(rows):
+                    step_losses.append(stepper.step(rows, rows_dev))
+                    continue
+                if tx is None:
+                    tx = BatchTiles(xtr, rows_dev, want_lib=False, rows_host=rows)
+                c = None if ctr is None else ctr[rows_dev]
+                if dist == 'gau':
+                    ty, lib = ytr_dense[rows_dev], None
+                else:
+                    ty = BatchTiles(ytr, rows_dev, want_lib=use_lib, rows_host=rows)
+                    lib = ty.lib.reshape(-1, 1) if use_lib else None
+                loss = self._train_step(tx, ty, lib, encoder, decoder, optimizer, dist, c, empty_somewhere)
+                step_losses.append(loss)
+                if concurrent:
+                    yield "step"
+            hist["train_loss"].extend(step_losses)
+            val_total_loss = float(self._eval_split(encoder, decoder, xva if shard is None else xva_cols, yva, cva,
+                                                    use_lib, dist, shard=shard).item())
+            hist["val_loss"].append(val_total_loss)
+            if scheduler is not None and optimizer.param_groups[0]['lr'] > 1e-7:
+                scheduler.step()
+            if val_total_loss < min_val:
+                no_improve, min_val = 0, val_total_loss
+                encoder_ckpt, decoder_ckpt = copy.deepcopy(encoder), copy.deepcopy(decoder)
+            else:
+                no_improve += 1
+            self._say(f"[{input_modality} -> {output_modality}] epoch {epoch + 1} validation loss {val_total_loss:.6f}")
+            if epoch > 1 and no_improve == patience:
+                self._say("Early Stopped!")
+                break
+            if concurrent:
+                yield "epoch"
+        hist["train_loss"] = [float(v) for v in torch.stack(hist["train_loss"]).cpu()] if hist["train_loss"] else []
+        if stepper is not None:
+            stepper.release()
+        key = input_modality + ' to ' + output_modality
+        self.history[key] = hist
+        encoder_dict[key] = copy.deepcopy(encoder_ckpt.eval())
+        decoder_dict[key] = copy.deepcopy(decoder_ckpt.eval())
+        if shard is not None:                 # the returned encoder holds the full first-layer weights on every rank
+            shard.unshard_module(encoder_dict[key])
+        if self.save_model is True:
+            if self.save_path is None:
+                self.save_path = os.getcwd()
+            torch.save(encoder_dict[key], self.save_path + '/encoder_' + input_modality + '_to_' + output_modality + '.pt')
+            torch.save(decoder_dict[key], self.save_path + '/decoder_' + input_modality + '_to_' + output_modality + '.pt')
+        self._say(f"Completed training for {input_modality} to {output_modality}")
+
     def train_predicting_networks(self, train_data_dict, val_data_dict, test_data_dict, batch_replay=None):
         """model.py:603-812.  `batch_replay`: optional {direction_index: [row-id arrays]} to replay a recorded batch
         order (parity tests); otherwise batches come from a DataLoader over row ids driven by the global torch RNG
@@ -903,113 +1065,23 @@ class scPair_object():
         self._precision()
         self.set_data(train_data_dict, val_data_dict, test_data_dict)
         encoder_dict, decoder_dict = {}, {}
+        concurrent = self._concurrent_directions_ok(batch_replay)
+        tasks = []
         for di, input_modality in enumerate(self.modalities.keys()):
-            output_modality = self._other(input_modality)
-            prediction_order = {'input': input_modality, 'output': output_modality}
-            self._say('Set up predicting networks:', prediction_order)
-            xtr = self._csr(train_data_dict, input_modality + '_train_mtx', as_input=True)
-            ytr = self._csr(train_data_dict, output_modality + '_train_mtx')
-            xva = self._csr(val_data_dict, input_modality + '_val_mtx', as_input=True)
-            yva = self._csr(val_data_dict, output_modality + '_val_mtx')
-            ctr = self._cov_dev(train_data_dict, input_modality + '_train_cov')
-            cva = self._cov_dev(val_data_dict, input_modality + '_val_cov')
-            n_cov = 0 if ctr is None else ctr.shape[1]
-            dist = self.modalities[output_modality]
-            encoder, decoder, use_lib = self._build_predictor(input_modality, output_modality, xtr.n_cols, ytr.n_cols, n_cov)
-            shard = None
-            if self.grad_sync is not None:
-                self._check_dp(encoder, decoder)
-                self.grad_sync.broadcast(list(encoder.parameters()) + list(decoder.parameters()) +
-                                         list(encoder.buffers()) + list(decoder.buffers()))
-                if self.shard_first_layer:
-                    if n_cov or self.batchnorm or dist == 'gau':
-                        raise ValueError("shard_first_layer needs cov=None, batchnorm=False and a count / Bernoulli output")
-                    from .distributed import FirstLayerShard
-                    shard = FirstLayerShard(self.grad_sync, xtr.n_cols)
-                    shard.shard_module(encoder)
-                    xtr_cols, xva_cols = shard.col_csr(xtr), shard.col_csr(xva)
-            optimizer = self._make_optimizer(encoder, decoder)
-            scheduler = self.get_scheduler(optimizer)
-            set_seed(self.SEED)
-            loader = _index_loader(xtr.n_rows, self.batch_size) if batch_replay is None else None
-            ytr_dense = ytr.to_dense().to(self.device) if dist == 'gau' else None
-            if not self.early_stopping_activation:
-                raise TypeError("early_stopping_activation=False is unusable upstream (model.py:719, 786: "
-                                "`val < None`); keep it True")
-            patience, no_improve, min_val = self.early_stopping_patience, 0, np.inf
-            hist = {"train_loss": [], "val_loss": []}
-            replay = None if batch_replay is None else list(batch_replay[di])
-            per_epoch = None if replay is None else int(np.ceil(xtr.n_rows / self.batch_size))
-            encoder_ckpt = decoder_ckpt = None
-            stepper = _GraphStepper(self, xtr, ytr, ctr, use_lib, encoder, decoder, optimizer, dist) \
-                if (self.capture_step and self.grad_sync is None and scheduler is None and dist != 'gau') else None
-            for epoch in range(self.max_epochs):
-                training_mode(encoder, decoder)
-                if replay is not None:
-                    batches = replay[epoch * per_epoch:(epoch + 1) * per_epoch]
-                    if not batches:
-                        break
-                else:
-                    batches = (b[0].numpy() for b in loader)
-                step_losses = []
-                for rows in batches:
-                    empty_somewhere = False
-                    tx = None
-                    if shard is not None:
-                        # feature-sharded first layer: the encoder input is the GLOBAL batch over this rank's columns
-                        tx, rows = shard.batch_tiles(xtr_cols, rows)
-                    elif self.grad_sync is not None:
-                        empty_somewhere = self.grad_sync.some_rank_empty(len(rows))
-                        self._bn_step(empty_somewhere)
-                        rows = self.grad_sync.shard(rows)
-                        if len(rows) == 0:            # global batch smaller than the world: join the collectives only
-                            step_losses.append(self._dp_step(None, 0.0, optimizer, True))
-                            continue
-                    rows = np.asarray(rows, dtype=np.int64)
-                    rows_dev = rows_to_device(rows, self.device)          # one upload, shared by both modalities
-                    if stepper is not None and stepper.wants(rows):
-                        step_losses.append(stepper.step(rows, rows_dev))
-                        continue
-                    if tx is None:
-                        tx = BatchTiles(xtr, rows_dev, want_lib=False, rows_host=rows)
-                    c = None if ctr is None else ctr[rows_dev]
-                    if dist == 'gau':
-                        ty, lib = ytr_dense[rows_dev], None
-                    else:
-                        ty = BatchTiles(ytr, rows_dev, want_lib=use_lib, rows_host=rows)
-                        lib = ty.lib.reshape(-1, 1) if use_lib else None
-                    loss = self._train_step(tx, ty, lib, encoder, decoder, optimizer, dist, c, empty_somewhere)
-                    step_losses.append(loss)
-                hist["train_loss"].extend(step_losses)
-                val_total_loss = float(self._eval_split(encoder, decoder, xva if shard is None else xva_cols, yva, cva,
-                                                        use_lib, dist, shard=shard).item())
-                hist["val_loss"].append(val_total_loss)
-                if scheduler is not None and optimizer.param_groups[0]['lr'] > 1e-7:
-                    scheduler.step()
-                if val_total_loss < min_val:
-                    no_improve, min_val = 0, val_total_loss
-                    encoder_ckpt, decoder_ckpt = copy.deepcopy(encoder), copy.deepcopy(decoder)
-                else:
-                    no_improve += 1
-                self._say(f"[{input_modality} -> {output_modality}] epoch {epoch + 1} validation loss {val_total_loss:.6f}")
-                if epoch > 1 and no_improve == patience:
-                    self._say("Early Stopped!")
-                    break
-            hist["train_loss"] = [float(v) for v in torch.stack(hist["train_loss"]).cpu()] if hist["train_loss"] else []
-            if stepper is not None:
-                stepper.release()
-            key = input_modality + ' to ' + output_modality
-            self.history[key] = hist
-            encoder_dict[key] = copy.deepcopy(encoder_ckpt.eval())
-            decoder_dict[key] = copy.deepcopy(decoder_ckpt.eval())
-            if shard is not None:                 # the returned encoder holds the full first-layer weights on every rank
-                shard.unshard_module(encoder_dict[key])
-            if self.save_model is True:
-                if self.save_path is None:
-                    self.save_path = os.getcwd()
-                torch.save(encoder_dict[key], self.save_path + '/encoder_' + input_modality + '_to_' + output_modality + '.pt')
-                torch.save(decoder_dict[key], self.save_path + '/decoder_' + input_modality + '_to_' + output_modality + '.pt')
-            self._say(f"Completed training for {input_modality} to {output_modality}")
+            task = self._predictor_task(di, input_modality, train_data_dict, val_data_dict, batch_replay, encoder_dict,
+                                        decoder_dict, concurrent)
+            if concurrent:
+                next(task)            # construction, initialisation, optimiser: in the reference's order, one direction at a time
+                tasks.append(task)
+            else:
+                for _ in task:        # the reference's order: this direction to completion before the next is set up
+                    pass
+        if concurrent:
+            self._run_interleaved(tasks)
+            order = [m + ' to ' + self._other(m) for m in self.modalities.keys()]
+            encoder_dict = {k: encoder_dict[k] for k in order}
+            decoder_dict = {k: decoder_dict[k] for k in order}
+            self.history.update({k: self.history.pop(k) for k in order})
         self.encoder_dict, self.decoder_dict = encoder_dict, decoder_dict
         ops.set_bn_sync(None)
         return encoder_dict, decoder_dict

@@ -70,6 +70,25 @@ def test_trajectory_with_captured_steps_is_bitwise_the_eager_one(monkeypatch):
         assert eager.history[k]["val_loss"] == graph.history[k]["val_loss"], k
 
 
+@pytest.mark.parametrize("name,precision", [("traj_nb_ber", "fp32"), ("traj_nb_ber_bn", "bf16"), ("traj_zinb_ber", "bf16")])
+def test_directions_side_by_side_equal_one_after_the_other(name, precision):
+    """The trainer runs the two predictors interleaved on two streams by default (scPair_object(concurrent_directions=True));
+    per-step training losses, per-epoch validation losses and the returned weights are bit for bit those of the reference's
+    order -- direction 0 to completion, then direction 1 (model.py:612) -- because each direction keeps its own stream of
+    batch draws (dropout 0 here: with dropout only the numbering of the mask seeds differs)."""
+    _, _, side = _run(name, precision)
+    _, _, seq = _run(name, precision, concurrent_directions=False)
+    assert list(side.history) == list(seq.history) and list(side.encoder_dict) == list(seq.encoder_dict)
+    for k in seq.history:
+        assert side.history[k]["train_loss"] == seq.history[k]["train_loss"], k
+        assert side.history[k]["val_loss"] == seq.history[k]["val_loss"], k
+    for k in seq.encoder_dict:
+        for (n1, a), (n2, b) in zip(side.encoder_dict[k].state_dict().items(), seq.encoder_dict[k].state_dict().items()):
+            assert n1 == n2 and torch.equal(a, b), (k, n1)
+        for (n1, a), (n2, b) in zip(side.decoder_dict[k].state_dict().items(), seq.decoder_dict[k].state_dict().items()):
+            assert n1 == n2 and torch.equal(a, b), (k, n1)
+
+
 @pytest.mark.parametrize("name", ["traj_nb_ber", "traj_zinb_ber", "traj_nb_ber_cov", "traj_nb_ber_bn"])
 def test_trajectory_fp32(name):
     d, c, obj = _run(name, "fp32")
