@@ -63,6 +63,13 @@ int scp_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst
 /* dst = bf16(relu(src)): the input of the ZINB zero-inflation layer pi = Linear(relu(z)) (model.py:240,255-256) */
 int scp_relu_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
 int scp_transpose_bf16(const float* src, int rows, int cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
+/* The same layer in the fp32-equivalent mode when the sparse operand is exact in bf16 (implicit ones: binarised peaks;
+ * utils.py:57 / model.py:128-140 with fp32 weights): the fp32 weights split into three bf16 planes hi | mid | lo,
+ * `plane` elements apart (scp_split3_bf16), X W^T = three launches of scp_spmm_fwd_bf16 into consecutive slabs; dY split
+ * and transposed as bf16 [N][ld_dst] with the three terms side by side, columns t * rows + r (scp_split3_transpose_bf16),
+ * dW = one launch of scp_spmm_dw_bf16 over a tile list of the minibatch repeated three times */
+int scp_split3_bf16(const float* src, long rows, long cols, long ld_src, void* dst_bf16, long ld_dst, long plane, void* stream);
+int scp_split3_transpose_bf16(const float* src, int rows, int cols, long ld_src, void* dst_bf16, long ld_dst, void* stream);
 int scp_spmm_fwd_bf16_min_split(int F);   /* smallest nsplit scp_spmm_fwd_bf16 accepts for F features */
 /* t_pk: the packed entries of scp_tiles_build; required when t_val is given (the kernels read them instead of key / val) */
 int scp_spmm_fwd_bf16(int ncells, int N, int F, const int32_t* t_ptr, const int32_t* t_key, const float* t_val,

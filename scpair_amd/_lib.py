@@ -65,6 +65,8 @@ _SIGS = {
     "scp_cast_bf16": (I, [P, L, L, L, P, L, P]),
     "scp_relu_cast_bf16": (I, [P, L, L, L, P, L, P]),
     "scp_transpose_bf16": (I, [P, I, I, L, P, L, P]),
+    "scp_split3_bf16": (I, [P, L, L, L, P, L, L, P]),
+    "scp_split3_transpose_bf16": (I, [P, I, I, L, P, L, P]),
     "scp_spmm_fwd_bf16_min_split": (I, [I]),
     "scp_spmm_fwd_bf16": (I, [I, I, I, P, P, P, P, P, L, P, L, I, P]),
     "scp_spmm_dw_bf16": (I, [I, I, I, P, P, P, P, P, L, P, L, P]),

@@ -914,6 +914,77 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* __rest
   }
 }
 
+// fp32 -> three bf16 planes hi | mid | lo (bf16_split<3>: hi + mid + lo carries 24 significant bits), each [rows][ldd],
+// `plane` elements apart: the operands of the fp32-equivalent first layer on the bf16 kernels when the sparse operand is
+// exact in bf16 (implicit ones): X W^T = X hi^T + X mid^T + X lo^T, three launches of the one-term kernel
+__global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restrict__ src, long rows, long cols, long lds_,
+                                                          __bf16* __restrict__ dst, long ldd, long plane) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  long n = rows * ldd;
+  if (i >= n) return;
+  long rr = i / ldd, c = i % ldd;
+  float v = (c < cols) ? src[rr * lds_ + c] : 0.f;
+  __bf16 t[3];
+  bf16_split<3>(v, t);
+  dst[i] = t[0];
+  dst[plane + i] = t[1];
+  dst[2 * plane + i] = t[2];
+}
+
+// fp32 [rows][cols] -> bf16 [cols][ldt] holding the three terms side by side: dst[c][t * rows + r] = term_t(src[r][c]);
+// columns 3 * rows .. ldt - 1 are zeroed.  With a tile list of the same minibatch repeated three times this makes
+// dW = dY^T X of the fp32-equivalent mode one launch of the one-term weight-gradient kernel over 3 * rows cells
+__global__ __launch_bounds__(256) void split3_transpose_bf16_kernel(const float* __restrict__ src, int rows, int cols,
+                                                                    long lds_, __bf16* __restrict__ dst, long ldt) {
+  __shared__ float tile[64][65];
+  int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    int rr = i >> 6, cc = i & 63;
+    tile[rr][cc] = (r0 + rr < rows && c0 + cc < cols) ? src[(long)(r0 + rr) * lds_ + c0 + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    int cc = i >> 6, rr = i & 63;
+    if (c0 + cc < cols && r0 + rr < rows) {
+      __bf16 t[3];
+      bf16_split<3>(tile[rr][cc], t);
+      __bf16* d = dst + (long)(c0 + cc) * ldt + r0 + rr;
+      d[0] = t[0];
+      d[rows] = t[1];
+      d[2 * (long)rows] = t[2];
+    }
+  }
+  // padding behind the three terms (the weight-gradient kernel reads whole 64-cell blocks)
+  if (blockIdx.y == 0) {
+    int pad = (int)(ldt - 3L * rows);
+    for (int i = threadIdx.x; i < 64 * pad; i += 256) {
+      int cc = i / pad, k = i % pad;
+      if (c0 + cc < cols) dst[(long)(c0 + cc) * ldt + 3L * rows + k] = (__bf16)0.f;
+    }
+  }
+}
+
+extern "C" int scp_split3_bf16(const float* src, long rows, long cols, long ld_src, void* dst, long ld_dst, long plane,
+                               void* stream_) {
+  SCP_CHECK(src && dst && rows > 0 && cols > 0 && ld_dst >= cols && plane >= rows * ld_dst, SCP_ERR_ARG,
+            "scp_split3_bf16: bad argument");
+  long n = rows * ld_dst;
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src, rows,
+                     cols, ld_src, (__bf16*)dst, ld_dst, plane);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
+extern "C" int scp_split3_transpose_bf16(const float* src, int rows, int cols, long ld_src, void* dst, long ld_dst,
+                                         void* stream_) {
+  SCP_CHECK(src && dst && rows > 0 && cols > 0 && ld_dst >= 3L * rows, SCP_ERR_ARG, "scp_split3_transpose_bf16: bad argument");
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(split3_transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream_, src, rows, cols, ld_src,
+                     (__bf16*)dst, ld_dst);
+  SCP_LAUNCH_CHECK();
+  return SCP_OK;
+}
+
 extern "C" int scp_cast_bf16(const float* src, long rows, long cols, long ld_src, void* dst, long ld_dst, void* stream_) {
   SCP_CHECK(src && dst && rows > 0 && cols > 0 && ld_dst >= cols, SCP_ERR_ARG, "scp_cast_bf16: bad argument");
   long n = rows * ld_dst;

@@ -685,6 +685,11 @@ class EncBranchesFn(torch.autograd.Function):
                   and shadows[0].shape[1] == shadows[1].shape[1]
                   and _rows_adjacent(shadows[0], shadows[1], 2 * shadows[0].shape[1]))
         groups = [list(range(nb))] if merged else [[i] for i in range(nb)]
+        # fp32-equivalent mode with implicit-ones data (binarised peaks): the sparse operand is exact in bf16, so the
+        # product needs only the three terms of the weights -- three launches of the one-term bf16 kernel (and one of its
+        # weight-gradient kernel over the minibatch repeated three times) instead of the general 6-product kernel
+        x3 = (ns == 3 and not use_bf and x.val is None and shd is None and 3 * Bg <= 32768 and Bg <= 16384
+              and not _os.environ.get("SCPAIR_FP32_GENERAL"))
         train = any(ctx.needs_input_grad)
         bns = [b_.get("bn") for b_ in cfg["br"]]
         has_bn = bns[0] is not None
@@ -696,14 +701,14 @@ class EncBranchesFn(torch.autograd.Function):
         nsplits, slab_sizes = [], []
         for g in groups:
             Hg = sum(H1s[i] for i in g)
-            if use_bf:
+            if use_bf or x3:
                 tiles_ = ((Bg + 255) // 256) * ((Hg + 127) // 128)
                 nsp = max(1, min(_cfg.get("fwd_wgs", 512) // max(tiles_, 1), ((F + 63) // 64) // 4, 16), L.scp_spmm_fwd_bf16_min_split(F))
             else:
                 nsp = _pick_split(Bg, Hg, F)
             nsp = L.scp_gemm_split_count(F, nsp)
             nsplits.append(nsp)
-            slab_sizes.append(nsp * Bg * Hg)
+            slab_sizes.append((3 if x3 else 1) * nsp * Bg * Hg)
         sizes = list(slab_sizes) + [Bn * n for n in nouts]
         if keep_saves:
             for i in range(nb):
@@ -728,6 +733,17 @@ class EncBranchesFn(torch.autograd.Function):
                                                sh.data_ptr(),
                                                sh.shape[1], slabs[gi].data_ptr(), Hg, nsplits[gi], stream),
                            "scp_spmm_fwd_bf16")
+            elif x3:
+                ldsh = (F + 63) // 64 * 64
+                sh3 = torch.empty((3, Hg, ldsh), dtype=torch.bfloat16, device=dev)
+                _lib.check(L.scp_split3_bf16(W1.data_ptr(), Hg, F, ldws[g[0]], sh3.data_ptr(), ldsh, Hg * ldsh, stream),
+                           "scp_split3_bf16")
+                for t3 in range(3):
+                    _lib.check(L.scp_spmm_fwd_bf16(Bg, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), None, None,
+                                                   sh3.data_ptr() + 2 * t3 * Hg * ldsh, ldsh,
+                                                   slabs[gi].data_ptr() + 4 * t3 * nsplits[gi] * Bg * Hg, Hg, nsplits[gi],
+                                                   stream), "scp_spmm_fwd_bf16")
+                nsplits[gi] *= 3                  # the tail sums all slabs
             else:
                 _lib.check(L.scp_spmm_fwd(Bg, Hg, F, _lib.ptr(x.ptr), _lib.ptr(x.key), _lib.ptr(x.val), W1.data_ptr(),
                                           ldws[g[0]], slabs[gi].data_ptr(), Hg, None, nsplits[gi], ns, stream), "scp_spmm_fwd")
@@ -781,7 +797,7 @@ class EncBranchesFn(torch.autograd.Function):
             ctx.save_for_backward(*[t for t in tensors if t is not None])
             ctx.present = [t is not None for t in tensors]
             ctx.dims = (Bn, F, H1s, H2s, N3s, ns, use_bf, groups, Cn, ldws)
-            ctx.shd = shd
+            ctx.shd, ctx.x3 = shd, x3
         return tuple(outs)
 
     @staticmethod
@@ -941,6 +957,7 @@ class EncBranchesFn(torch.autograd.Function):
                     dy1_of[i] = shd.sync.gather_rows(d_.view(-1)).view(Bg, H1s[i])
         # ---- first-layer weight gradient (and, where registered, the AdamW step in its epilogue) -------------------
         tp, tk, tv, tpk = _lib.ptr(t.ptr), _lib.ptr(t.key), _lib.ptr(t.val), _lib.ptr(t.pk)
+        tiles3 = None
         Bn = Bg
         for u, mode, payload in plan:
             Hu = sum(H1s[i] for i in u)
@@ -948,6 +965,19 @@ class EncBranchesFn(torch.autograd.Function):
             if mode == "plain32":
                 i = u[0]
                 dy1_ptr = dy1_of[i].data_ptr() if shd is not None else arr[i].dY1
+                if ctx.x3:
+                    # dW = dY^T X with dY in three bf16 terms and X exact: the one-term kernel over the minibatch three times
+                    if tiles3 is None:
+                        tiles3 = BatchTiles(t.csr, t.rows.repeat(3), want_lib=False, capacity=3 * int(t.nnz))
+                    ldt3 = (3 * Bn + 63) // 64 * 64
+                    dyt3 = torch.empty((H1s[i], ldt3), dtype=torch.bfloat16, device=dev)
+                    keep.append(dyt3)
+                    _lib.check(L.scp_split3_transpose_bf16(dy1_ptr, Bn, H1s[i], H1s[i], dyt3.data_ptr(), ldt3, stream),
+                               "scp_split3_transpose_bf16")
+                    _lib.check(L.scp_spmm_dw_bf16(3 * Bn, H1s[i], F, _lib.ptr(tiles3.ptr), _lib.ptr(tiles3.key), None, None,
+                                                  dyt3.data_ptr(), ldt3, payload.data_ptr(), Ft, stream), "scp_spmm_dw_bf16")
+                    grads[i][0] = payload
+                    continue
                 _lib.check(L.scp_spmm_dw(Bn, H1s[i], F, tp, tk, tv, dy1_ptr, H1s[i], payload.data_ptr(), Ft, ns, stream),
                            "scp_spmm_dw")
                 grads[i][0] = payload
@@ -981,6 +1011,7 @@ class EncBranchesFn(torch.autograd.Function):
                     grads[i][0] = payload[row_:row_ + H1s[i]]
                     row_ += H1s[i]
         ctx.buf = ctx.tiles = ctx.arr = ctx.cov = ctx.shd = None
+        del tiles3
         flat = [None, None]
         for i in range(nb):
             flat += grads[i]

@@ -113,6 +113,51 @@ def test_encoder_branch_vs_fp64(B, F, H1, H2, N3, prec):
         S.set_precision("fp32")
 
 
+@pytest.mark.parametrize("B,F,H1,H2,N3,C", [(1024, 2000, 900, 40, 40, 0), (203, 515, 128, 8, 1, 0), (67, 333, 16, 8, 0, 5),
+                                            (9, 100, 4, 1, 1, 0), (300, 1001, 800, 30, 30, 4)])
+def test_binary_input_fp32_mode_three_term_path(B, F, H1, H2, N3, C, monkeypatch):
+    """fp32-equivalent mode with implicit-ones data (binarised peaks): the first layer runs three launches of the one-term
+    bf16 kernel on the hi / mid / lo planes of the weights (scp_split3_bf16) and its weight gradient one launch over the
+    minibatch repeated three times with dY split the same way (scp_split3_transpose_bf16) -- against the fp64 formula at
+    the fp32 tolerance of test_encoder_branch_vs_fp64, and against the general 6-product kernel (SCPAIR_FP32_GENERAL=1)."""
+    import scipy.sparse as sp
+    import scpair_amd as S
+    from scpair_amd import ops
+    S.set_precision("fp32")
+    rng = np.random.default_rng(B + F)
+    m = sp.random(B + 11, F, density=0.06, format="csr", random_state=np.random.RandomState(5), dtype=np.float32)
+    m.data[:] = 1.0
+    m.sort_indices()
+    rows = rng.permutation(B + 11)[:B]
+    x = torch.tensor(np.asarray(m[rows].todense(), dtype=np.float32))
+    gc = torch.Generator().manual_seed(3)
+    cov = torch.randn(B, C, generator=gc) if C else None
+    g, P, q, out_r = _draw(F, H1, H2, N3, x, lambda t: t.double(), H1 + N3, cov=cov)
+    wout = torch.randn(B, N3 if N3 else H2, generator=g)
+    (out_r * wout.double()).sum().backward()
+    csr = S.DeviceCSR.from_scipy(m, DEV, binary=True)
+    assert csr.values is None
+    res = {}
+    for mode in ("three-term", "general"):
+        if mode == "general":
+            monkeypatch.setenv("SCPAIR_FP32_GENERAL", "1")
+        d = {k: v.clone().to(DEV).requires_grad_(True) for k, v in P.items()}
+        tiles = S.BatchTiles(csr, rows)
+        br = dict(W1=d["W1"], b1=d["b1"], g1=d["g1"], be1=d["be1"], W2=d["W2"], b2=d["b2"], g2=d["g2"], be2=d["be2"],
+                  W3=d.get("W3"), b3=d.get("b3"))
+        out = ops.enc_branches(tiles, [br], 0.01, cov=None if cov is None else cov.to(DEV))[0]
+        (out * wout.to(DEV)).sum().backward()
+        _check("out/" + mode, out, out_r, 2e-4)
+        for k in P:
+            _check(k + "/" + mode, d[k].grad, q[k].grad, 2e-4)
+        with torch.no_grad():
+            out_e = ops.enc_branches(tiles, [br], 0.01, cov=None if cov is None else cov.to(DEV))[0]
+        assert torch.equal(out_e, out.detach())
+        res[mode] = (out.detach(), d["W1"].grad.detach())
+    _check("out three-term vs general", res["three-term"][0], res["general"][0].cpu(), 2e-5)
+    _check("dW1 three-term vs general", res["three-term"][1], res["general"][1].cpu(), 2e-5)
+
+
 def _mask(ops, seed, B, H, p):
     """The dropout factors keep_scale(seed, row * H + col, p) of a [B, H] layer, read off the generic FCNN layer kernel
     (same counter-based hash): input 1, weight 1, no LayerNorm, identity activation."""

@@ -378,8 +378,11 @@ def test_whole_paired_step_c2_shape_vs_oracle(prec, zinb):
                                 continue
                             d_ = (v.detach().cpu() - sd[k].detach()).abs()
                             if prec == "fp32":
-                                frac = float((d_ < 2e-3 * lr + 1e-7).float().mean())
-                                assert frac > 0.99 and float(d_.max()) <= 2.001 * lr, (dist_, tag, k, frac, float(d_.max()) / lr)
+                                # (at most 1 % of the entries -- one entry for the 40-element vectors -- outside)
+                                n_out = int((d_ >= 2e-3 * lr + 1e-7).sum())
+                                frac = 1.0 - n_out / d_.numel()
+                                assert n_out <= max(1, d_.numel() // 100) and float(d_.max()) <= 2.001 * lr, \
+                                    (dist_, tag, k, frac, float(d_.max()) / lr)
                             elif v.ndim == 2 and v.numel() > 1_000_000:
                                 frac = float((d_ < 0.2 * lr).float().mean())
                                 assert frac > 0.97 and float(d_.max()) <= 2.001 * lr, (dist_, tag, k, frac, float(d_.max()) / lr)
