@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--explicit-peak-values", action="store_true",
                     help="hold the binary peak matrices WITH a value array of ones (what the trainer's data seam did with a "
                          "binarised scipy matrix before it detected all-ones data): the value-carrying kernel paths")
+    ap.add_argument("--zinb", action="store_true", help="ZINB likelihood for the RNA output (the live G x G zero-inflation layer: C3)")
     ap.add_argument("--sequential", action="store_true",
                     help="train the predictors one after the other (the reference's order) instead of side by side")
     ap.add_argument("--profile", default=None, help="write a cProfile listing (by cumulative time) of the longer run here")
@@ -75,9 +76,9 @@ def main():
     def run(epochs):
         if a.vae:
             return run_vae(epochs)
-        obj = S.scPair_object(None, cov=None, modalities={"Gene Expression": "nb", "Peaks": "ber"}, SEED=0,
-                              hidden_layer=[900, 40], dropout_rate=0.1, batch_size=a.batch, max_epochs=epochs,
-                              early_stopping_patience=1000, device=dev, save_model=False, zero_inflated=False,
+        obj = S.scPair_object(None, cov=None, modalities={"Gene Expression": "zinb" if a.zinb else "nb", "Peaks": "ber"},
+                              SEED=0, hidden_layer=[900, 40], dropout_rate=0.1, batch_size=a.batch, max_epochs=epochs,
+                              early_stopping_patience=1000, device=dev, save_model=False, zero_inflated=bool(a.zinb),
                               use_mixed_precision=(a.precision == "bf16"), verbose=False, grad_sync=sync,
                               shard_first_layer=(a.dp == "sharded"), concurrent_directions=not a.sequential)
         torch.cuda.synchronize()
@@ -115,7 +116,7 @@ def main():
                  ("one after the other" if (a.sequential or a.dp != "none") else "side by side on two streams")) +
                 "; marginal cost of an epoch (training steps + validation over the val split + deepcopy of the best modules) "
                 "from two runs",
-        "data_parallel": a.dp, "sequential": bool(a.sequential), "explicit_peak_values": bool(a.explicit_peak_values), "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
+        "zinb": bool(a.zinb), "data_parallel": a.dp, "sequential": bool(a.sequential), "explicit_peak_values": bool(a.explicit_peak_values), "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
         "seconds": [round(t_lo, 4), round(t_hi, 4)],
         "ms_per_epoch_pair": round(1e3 * per_epoch, 3),
         "ms_per_direction_step_incl_validation": round(1e3 * per_epoch / steps_per_epoch, 4),
