@@ -36,6 +36,9 @@ def main():
                     help="hold the binary peak matrices WITH a value array of ones (what the trainer's data seam did with a "
                          "binarised scipy matrix before it detected all-ones data): the value-carrying kernel paths")
     ap.add_argument("--zinb", action="store_true", help="ZINB likelihood for the RNA output (the live G x G zero-inflation layer: C3)")
+    ap.add_argument("--cov", type=int, default=0, help="one-hot covariate block of this many levels (cov=[...] of the constructor)")
+    ap.add_argument("--batchnorm", action="store_true")
+    ap.add_argument("--hidden", type=int, nargs=2, default=[900, 40])
     ap.add_argument("--sequential", action="store_true",
                     help="train the predictors one after the other (the reference's order) instead of side by side")
     ap.add_argument("--profile", default=None, help="write a cProfile listing (by cumulative time) of the longer run here")
@@ -59,8 +62,12 @@ def main():
     dicts = []
     for split in ("train", "val", "test"):
         r, p = splits[split]
+        cov = None
+        if a.cov:
+            g_ = torch.Generator().manual_seed(7 + len(dicts))
+            cov = torch.nn.functional.one_hot(torch.randint(0, a.cov, (r.n_rows,), generator=g_), a.cov).float()
         dicts.append({f"Gene Expression_{split}_mtx": r, f"Peaks_{split}_mtx": p,
-                      f"Gene Expression_{split}_cov": None, f"Peaks_{split}_cov": None})
+                      f"Gene Expression_{split}_cov": cov, f"Peaks_{split}_cov": cov})
 
     def run_vae(epochs):
         obj = S.scVAE_object(distribution="nb", SEED=0, hidden_dim=[900], latent_dim=40, dropout_rate=0.1, batch_size=a.batch,
@@ -76,8 +83,9 @@ def main():
     def run(epochs):
         if a.vae:
             return run_vae(epochs)
-        obj = S.scPair_object(None, cov=None, modalities={"Gene Expression": "zinb" if a.zinb else "nb", "Peaks": "ber"},
-                              SEED=0, hidden_layer=[900, 40], dropout_rate=0.1, batch_size=a.batch, max_epochs=epochs,
+        obj = S.scPair_object(None, cov=(["labels"] if a.cov else None),
+                              modalities={"Gene Expression": "zinb" if a.zinb else "nb", "Peaks": "ber"},
+                              SEED=0, hidden_layer=list(a.hidden), batchnorm=a.batchnorm, dropout_rate=0.1, batch_size=a.batch, max_epochs=epochs,
                               early_stopping_patience=1000, device=dev, save_model=False, zero_inflated=bool(a.zinb),
                               use_mixed_precision=(a.precision == "bf16"), verbose=False, grad_sync=sync,
                               shard_first_layer=(a.dp == "sharded"), concurrent_directions=not a.sequential)
@@ -116,7 +124,7 @@ def main():
                  ("one after the other" if (a.sequential or a.dp != "none") else "side by side on two streams")) +
                 "; marginal cost of an epoch (training steps + validation over the val split + deepcopy of the best modules) "
                 "from two runs",
-        "zinb": bool(a.zinb), "data_parallel": a.dp, "sequential": bool(a.sequential), "explicit_peak_values": bool(a.explicit_peak_values), "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
+        "zinb": bool(a.zinb), "cov": a.cov, "batchnorm": bool(a.batchnorm), "hidden": list(a.hidden), "data_parallel": a.dp, "sequential": bool(a.sequential), "explicit_peak_values": bool(a.explicit_peak_values), "precision": a.precision, "cells": a.cells, "val_cells": a.val, "batch": a.batch, "epochs": a.epochs,
         "seconds": [round(t_lo, 4), round(t_hi, 4)],
         "ms_per_epoch_pair": round(1e3 * per_epoch, 3),
         "ms_per_direction_step_incl_validation": round(1e3 * per_epoch / steps_per_epoch, 4),
