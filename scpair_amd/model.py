@@ -328,15 +328,80 @@ def _to_csr(v, device, binary=None):
     return DeviceCSR.from_scipy(v, device, binary=binary)
 
 
-def _index_loader(n, batch_size, drop_last=False):
-    """A DataLoader over row ids with the samplers the reference's loader builds (model.py:713-717: shuffle=True,
-    num_workers=0 -> BatchSampler(RandomSampler(dataset), batch_size, drop_last)), so it draws from the global torch RNG the
-    same way and yields the same batch composition.  The batch sampler is handed over as `sampler` with automatic batching
-    off: the dataset is then indexed once per BATCH instead of once per row and nothing is collated (1024 `__getitem__`
-    calls and a stack per batch cost 2.4 ms of host time, more than the training step itself)."""
+class _FastIndexLoader:
+    """What DataLoader(TensorDataset(arange(n)), batch_size, shuffle=True, num_workers=0) yields, without its per-row Python
+    work: the same two draws from the global torch RNG per epoch -- the iterator's base seed when it is created
+    (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__) and the RandomSampler's private seed when the first batch
+    is asked for (sampler.py, RandomSampler.__iter__) -- then slices of randperm(n) from that private generator.  It follows
+    torch's internals, so _index_loader() checks it against the real DataLoader once per process and uses that instead if
+    they ever disagree."""
+
+    def __init__(self, n, batch_size, drop_last=False):
+        self.n, self.batch_size, self.drop_last = int(n), int(batch_size), bool(drop_last)
+
+    def __len__(self):
+        return self.n // self.batch_size if self.drop_last else -(-self.n // self.batch_size)
+
+    def __iter__(self):
+        torch.empty((), dtype=torch.int64).random_()              # the iterator's base seed (unused without workers)
+        return self._batches()
+
+    def _batches(self):
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        g = torch.Generator()
+        g.manual_seed(seed)
+        perm = torch.randperm(self.n, generator=g)
+        for i in range(0, self.n, self.batch_size):
+            idx = perm[i:i + self.batch_size]
+            if self.drop_last and idx.shape[0] < self.batch_size:
+                break
+            yield (idx,)
+
+
+def _dataloader_over_indices(n, batch_size, drop_last=False):
+    """The reference's loader (model.py:713-717: shuffle=True, num_workers=0 -> BatchSampler(RandomSampler(dataset), batch_size,
+    drop_last)) over row ids, with the batch sampler handed over as `sampler` and automatic batching off: the dataset is
+    indexed once per BATCH instead of once per row and nothing is collated (1024 `__getitem__` calls and a stack per batch
+    cost 2.4 ms of host time, more than the training step itself).  Same draws from the global RNG, same batches."""
     ds = torch.utils.data.TensorDataset(torch.arange(n))
     batches = torch.utils.data.BatchSampler(torch.utils.data.RandomSampler(ds), batch_size, drop_last)
     return torch.utils.data.DataLoader(ds, batch_size=None, sampler=batches, num_workers=0)
+
+
+_fast_loader_ok = None
+
+
+def _fast_loader_matches_dataloader():
+    """One-time check (forked RNG, a 23-row dataset, two epochs, both drop_last settings): _FastIndexLoader yields the
+    DataLoader's batches and leaves the global RNG in the same state."""
+    global _fast_loader_ok
+    if _fast_loader_ok is None:
+        ok = True
+        try:
+            with torch.random.fork_rng(devices=[]):
+                for drop_last in (False, True):
+                    out = []
+                    for make in (_dataloader_over_indices, _FastIndexLoader):
+                        torch.manual_seed(20240229)
+                        ld = make(23, 5, drop_last)
+                        got = [[b[0].clone() for b in ld] for _ in range(2)]
+                        out.append((got, torch.get_rng_state()))
+                    (a, sa), (b, sb) = out
+                    ok = ok and bool((sa == sb).all()) and all(
+                        len(x) == len(y) and all(p.dtype == q.dtype and torch.equal(p, q) for p, q in zip(x, y))
+                        for x, y in zip(a, b))
+        except Exception:
+            ok = False
+        _fast_loader_ok = ok
+    return _fast_loader_ok
+
+
+def _index_loader(n, batch_size, drop_last=False):
+    """Shuffled minibatches of row ids, drawn from the global torch RNG the way the reference's DataLoader draws them
+    (model.py:713-717), so batch composition and order are the reference's for the same seed."""
+    if _fast_loader_matches_dataloader() and not os.environ.get("SCPAIR_TORCH_DATALOADER"):
+        return _FastIndexLoader(n, batch_size, drop_last)
+    return _dataloader_over_indices(n, batch_size, drop_last)
 
 
 class _GraphStepper:

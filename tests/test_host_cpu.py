@@ -51,24 +51,27 @@ def test_batch_order_equals_reference():
 
 @pytest.mark.parametrize("n,bs,drop_last", [(1000, 130, False), (1000, 130, True), (7, 3, False), (5, 8, False)])
 def test_index_loader_is_the_shuffling_dataloader(n, bs, drop_last):
-    """_index_loader indexes its dataset once per batch; batches, their order over several epochs, and the state the
-    global torch RNG is left in are those of DataLoader(TensorDataset(arange(n)), batch_size, shuffle=True), which is
-    what the reference builds (model.py:713-717)."""
+    """_index_loader yields slices of the sampler's permutation without the DataLoader's per-row work; batches, their order
+    over several epochs, and the state the global torch RNG is left in are those of DataLoader(TensorDataset(arange(n)),
+    batch_size, shuffle=True), which is what the reference builds (model.py:713-717)."""
     from scpair_amd.model import _index_loader
     ds = torch.utils.data.TensorDataset(torch.arange(n))
     torch.manual_seed(11)
     ref = torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=True, num_workers=0, drop_last=drop_last)
     want = [[b[0].numpy().copy() for b in ref] for _ in range(3)]
     rng_want = torch.get_rng_state()
-    torch.manual_seed(11)
-    mine = _index_loader(n, bs, drop_last)
-    got = [[b[0].numpy().copy() for b in mine] for _ in range(3)]
-    assert bool((torch.get_rng_state() == rng_want).all())
-    for e_want, e_got in zip(want, got):
-        assert len(e_want) == len(e_got)
-        for a, b in zip(e_want, e_got):
-            assert a.dtype == b.dtype
-            np.testing.assert_array_equal(a, b)
+    from scpair_amd.model import _FastIndexLoader, _dataloader_over_indices, _fast_loader_matches_dataloader
+    assert _fast_loader_matches_dataloader() and isinstance(_index_loader(n, bs, drop_last), _FastIndexLoader)
+    for make in (_index_loader, _dataloader_over_indices):        # the lean iterator in use, and the fall-back behind it
+        torch.manual_seed(11)
+        mine = make(n, bs, drop_last)
+        got = [[b[0].numpy().copy() for b in mine] for _ in range(3)]
+        assert bool((torch.get_rng_state() == rng_want).all())
+        for e_want, e_got in zip(want, got):
+            assert len(e_want) == len(e_got)
+            for a, b in zip(e_want, e_got):
+                assert a.dtype == b.dtype
+                np.testing.assert_array_equal(a, b)
 
 
 def test_all_ones_matrices_are_held_without_values():
