@@ -1120,6 +1120,8 @@ class scPair_object():
             torch.save(encoder_dict[key], self.save_path + '/encoder_' + input_modality + '_to_' + output_modality + '.pt')
             torch.save(decoder_dict[key], self.save_path + '/decoder_' + input_modality + '_to_' + output_modality + '.pt')
         self._say(f"Completed training for {input_modality} to {output_modality}")
+        if concurrent:
+            self._rng_after[di] = rng_state
 
     def train_predicting_networks(self, train_data_dict, val_data_dict, test_data_dict, batch_replay=None):
         """model.py:603-812.  `batch_replay`: optional {direction_index: [row-id arrays]} to replay a recorded batch
@@ -1142,7 +1144,10 @@ class scPair_object():
                 for _ in task:        # the reference's order: this direction to completion before the next is set up
                     pass
         if concurrent:
+            self._rng_after = {}
             self._run_interleaved(tasks)
+            # the global torch RNG is left where the one-after-the-other order leaves it: behind the last direction's draws
+            torch.set_rng_state(self._rng_after[len(tasks) - 1])
             order = [m + ' to ' + self._other(m) for m in self.modalities.keys()]
             encoder_dict = {k: encoder_dict[k] for k in order}
             decoder_dict = {k: decoder_dict[k] for k in order}

@@ -77,7 +77,9 @@ def test_directions_side_by_side_equal_one_after_the_other(name, precision):
     order -- direction 0 to completion, then direction 1 (model.py:612) -- because each direction keeps its own stream of
     batch draws (dropout 0 here: with dropout only the numbering of the mask seeds differs)."""
     _, _, side = _run(name, precision)
+    rng_side = torch.get_rng_state()
     _, _, seq = _run(name, precision, concurrent_directions=False)
+    assert bool((torch.get_rng_state() == rng_side).all())          # the global RNG is left in the same state, too
     assert list(side.history) == list(seq.history) and list(side.encoder_dict) == list(seq.encoder_dict)
     for k in seq.history:
         assert side.history[k]["train_loss"] == seq.history[k]["train_loss"], k
