@@ -328,6 +328,23 @@ def _to_csr(v, device, binary=None):
     return DeviceCSR.from_scipy(v, device, binary=binary)
 
 
+def _snapshot(src, dst=None):
+    """The best-so-far copy of a module that the epoch loops keep (the reference deep-copies the module every time the
+    validation loss improves, model.py:790-792): the first call makes the deep copy, later calls overwrite its parameters
+    and buffers in place -- the same values without rebuilding the module tree and re-allocating its tensors every epoch."""
+    if dst is None or os.environ.get("SCPAIR_DEEPCOPY_CHECKPOINTS"):
+        return copy.deepcopy(src)
+    with torch.no_grad():
+        to = list(dst.parameters()) + list(dst.buffers())
+        frm = list(src.parameters()) + list(src.buffers())
+        if len(to) != len(frm) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(to, frm)):
+            return copy.deepcopy(src)
+        if to:
+            torch._foreach_copy_(to, frm)
+    dst.train(src.training)
+    return dst
+
+
 class _FastIndexLoader:
     """What DataLoader(TensorDataset(arange(n)), batch_size, shuffle=True, num_workers=0) yields, without its per-row Python
     work: the same two draws from the global torch RNG per epoch -- the iterator's base seed when it is created
@@ -1096,7 +1113,7 @@ class scPair_object():
                 scheduler.step()
             if val_total_loss < min_val:
                 no_improve, min_val = 0, val_total_loss
-                encoder_ckpt, decoder_ckpt = copy.deepcopy(encoder), copy.deepcopy(decoder)
+                encoder_ckpt, decoder_ckpt = _snapshot(encoder, encoder_ckpt), _snapshot(decoder, decoder_ckpt)
             else:
                 no_improve += 1
             self._say(f"[{input_modality} -> {output_modality}] epoch {epoch + 1} validation loss {val_total_loss:.6f}")
@@ -1234,7 +1251,7 @@ class scPair_object():
                     scheduler.step()
                 if val_total_loss < min_val:
                     no_improve, min_val = 0, val_total_loss
-                    ckpt = copy.deepcopy(mapping_network)
+                    ckpt = _snapshot(mapping_network, ckpt)
                 else:
                     no_improve += 1
                 if epoch > 1 and no_improve == patience:
@@ -1351,7 +1368,7 @@ class scPair_object():
             hist["val_loss"].append(val_total_loss)
             if val_total_loss < min_val:
                 no_improve, min_val = 0, val_total_loss
-                self.augment_encoder_ckpt = copy.deepcopy(enc)
+                self.augment_encoder_ckpt = _snapshot(enc, self.augment_encoder_ckpt)
             else:
                 no_improve += 1
             if epoch > 1 and no_improve == patience:

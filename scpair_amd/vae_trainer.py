@@ -118,7 +118,7 @@ class scVAE_object:
         """train_mtx / val_mtx: dense tensor, scipy sparse or DeviceCSR [cells x features]; covariates: [cells x C]
         tensors or None.  `batch_replay`: optional list of row-id arrays (parity tests); `init_state`: optional
         (encoder_state_dict, decoder_state_dict) to start from.  Returns (encoder, decoder): the best-validation copies."""
-        from .model import _index_loader, _to_csr
+        from .model import _index_loader, _snapshot, _to_csr
         if self.device.type != "cuda":
             raise RuntimeError("scpair_amd trains on a GPU only (device must be cuda); there is no CPU path")
         ops.set_precision("bf16" if self.use_mixed_precision else "fp32")
@@ -177,7 +177,7 @@ class scVAE_object:
             self._say(f"[VAE] epoch {epoch + 1} validation total {vt:.6f} (reconstruction {vr:.6f}, KL {vk:.6f})")
             if vt < min_val:
                 no_improve, min_val = 0, vt
-                best = (copy.deepcopy(enc), copy.deepcopy(dec))
+                best = (_snapshot(enc, None if best is None else best[0]), _snapshot(dec, None if best is None else best[1]))
             else:
                 no_improve += 1
             if epoch > 1 and no_improve == patience:
