@@ -103,6 +103,32 @@ def test_all_ones_matrices_are_held_without_values():
     del rng
 
 
+def test_checkpoint_snapshot_equals_deepcopy():
+    """model._snapshot: the epoch loops' best-so-far copy -- a deep copy the first time, overwritten in place afterwards:
+    the values of a deep copy (parameters and buffers, BatchNorm's counters included), no aliasing with the live module."""
+    import copy
+    from scpair_amd.model import _snapshot
+    torch.manual_seed(0)
+    live = nn.Sequential(nn.Linear(6, 5), nn.BatchNorm1d(5), nn.LeakyReLU(), nn.Linear(5, 3))
+    live.train()
+    live(torch.randn(8, 6))
+    snap = _snapshot(live)
+    ids = [id(p) for p in snap.parameters()]
+    assert all(a is not b and torch.equal(a, b) for a, b in zip(snap.state_dict().values(), live.state_dict().values()))
+    with torch.no_grad():
+        for p in live.parameters():
+            p.add_(1.0)
+    live(torch.randn(8, 6))
+    want = copy.deepcopy(live)
+    assert not torch.equal(snap[0].weight, live[0].weight)                  # the snapshot did not follow the live module
+    snap2 = _snapshot(live.eval(), snap)
+    assert snap2 is snap and [id(p) for p in snap.parameters()] == ids and not snap.training
+    for (k, a), (_, b) in zip(snap.state_dict().items(), want.state_dict().items()):
+        assert torch.equal(a, b), k
+    other = nn.Sequential(nn.Linear(6, 4))
+    assert _snapshot(other, snap) is not snap                               # another architecture: a fresh deep copy
+
+
 def test_weight_decay_groups_equal_reference():
     with open(os.path.join(U.GOLD, "weight_decay_groups.json")) as f:
         groups = json.load(f)
